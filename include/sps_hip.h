@@ -1,0 +1,138 @@
+/* sps_hip.h -- C ABI of libsps_hip.so: the MI355X (gfx950) native implementation of the
+ * SPS per-scan sparse-convnet hot path.
+ *
+ * The reference (ibrahimhroob/SPS) has no native code of its own; the native boundary it
+ * crosses on this path is MinkowskiEngine's pybind11 module (MinkowskiEngineBackend._C:
+ * CoordinateMapManager, ConvolutionForwardGPU, ...), reached from the Python call sites
+ * cited next to each entry point below.  This header is what a maintainer binds INSTEAD of
+ * MinkowskiEngine for that path (ctypes stub: INTEGRATION.md).
+ *
+ * Conventions
+ *   - every function returns SPS_OK (0) or a negative error code; the message for the last
+ *     error on the calling thread is available from sps_last_error();
+ *   - no exceptions and no torch types cross the boundary: plain pointers and sizes;
+ *   - pointers named *_dev are DEVICE pointers owned by the caller (torch tensors'
+ *     data_ptr()); *_host are host pointers; the library owns only what lives inside ctx
+ *     (arena, hash tables, weights);
+ *   - one ctx per (process, device); a ctx is not thread-safe; all work is ordered on the
+ *     hipStream_t passed as `stream` (void*, NULL = the default stream) and functions do
+ *     not synchronise with the host unless their comment says so.
+ */
+#ifndef SPS_HIP_H
+#define SPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPS_OK 0
+#define SPS_ERR_INVALID (-1) /* bad argument / state                              */
+#define SPS_ERR_HIP (-2)     /* a HIP runtime call failed                        */
+#define SPS_ERR_NOMEM (-3)   /* device allocation failed                         */
+#define SPS_ERR_RANGE (-4)   /* a coordinate does not fit the 64-bit voxel key   */
+#define SPS_ERR_NOWEIGHTS (-5)
+
+#define SPS_NUM_LEVELS 5 /* tensor strides 1,2,4,8,16 (minkunet.py:161-219) */
+
+/* Voxel-key range (sps_amd/csrc/sps_hip.hip packs (b,x,y,z,t) into 64 bits):
+ * x,y,z in [-131072, 131071] voxels, t in [-16, 15], b in [0, 30]. */
+#define SPS_COORD_MIN (-131072)
+#define SPS_COORD_MAX (131071)
+#define SPS_T_MIN (-16)
+#define SPS_T_MAX (15)
+#define SPS_BATCH_MAX (30)
+
+typedef struct sps_ctx sps_ctx;
+
+const char *sps_last_error(void);
+int sps_version(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+/* Replaces the per-forward ME coordinate manager + the module's .cuda() placement
+ * (reference scripts/predict.py:59, src/sps/datasets/util.py:40). */
+int sps_ctx_create(int device, sps_ctx **out);
+int sps_ctx_destroy(sps_ctx *ctx);
+/* Pre-size the arena for clouds of up to max_points rows (optional: sps_forward grows it
+ * on demand, which synchronises the device). */
+int sps_reserve(sps_ctx *ctx, int64_t max_points);
+
+/* ---- weights ------------------------------------------------------------------------
+ * Replaces nn.Module.load_state_dict on CustomMinkUNet (reference scripts/predict.py:56-58,
+ * src/sps/datasets/util.py:33-39).  The blob is the concatenation of the tensors listed by
+ * sps_weights_tensor_info in index order; names are the reference state_dict keys without
+ * the "model.MinkUNet." prefix, e.g. "block2.0.conv1.kernel" [81,8,16],
+ * "block2.0.downsample.0.kernel" [8,16], "bn0.bn.running_var" [8], "final.bias" [1]. */
+int sps_weights_num_tensors(void);
+int sps_weights_tensor_info(int idx, char *name, int name_cap, int64_t *offset, int64_t *numel);
+int64_t sps_weights_numel(void);
+/* Copies the blob to the device and derives the folded BatchNorm scale/shift
+ * (eval mode, eps = 1e-5).  Synchronises. */
+int sps_weights_load(sps_ctx *ctx, const float *blob_host, int64_t numel);
+
+/* ---- forward ------------------------------------------------------------------------
+ * Replaces SPSModel.forward (reference src/sps/models/models.py:20-30): quantise by
+ * [1,vs,vs,vs,1] in f32, floor, unique voxels + inverse map, CustomMinkUNet (33 sparse
+ * convs + eval BN + ReLU + residual + concat), slice back to points, sigmoid.
+ *   coords_dev : float32 rows (b,x,y,z,t,...) with row stride `ld` floats (ld >= 5)
+ *   scores_dev : float32 [n]
+ * Rows whose voxel does not fit the key range get score NaN and the call that next
+ * synchronises (sps_metrics / sps_check) reports SPS_ERR_RANGE. */
+int sps_forward(sps_ctx *ctx, const float *coords_dev, int64_t ld, int64_t n, float voxel_size,
+                float *scores_dev, void *stream);
+/* Synchronises `stream` and returns SPS_ERR_RANGE if any forward since the last check
+ * met an unrepresentable coordinate. */
+int sps_check(sps_ctx *ctx, void *stream);
+
+/* ---- metrics ------------------------------------------------------------------------
+ * Replaces the per-scan part of SPSNet.predict_step (reference models.py:84-105) +
+ * util.calculate_metrics (util.py:285-299).  For every batch index b < n_batches it
+ * accumulates over the rows with t == 1 (scan rows):
+ *   out[b*8+0..7] = count, TP, FP, FN, TN, sum (s-g)^2, sum g, sum g^2
+ * with pred = s < eps ? 0 : 1, gt = g < eps ? 0 : 1 (float32 compares), positive = 1.
+ *   batch_dev : float32 rows (b,x,y,z,t,label) with row stride ld (ld >= 6)
+ * Synchronises `stream` (copies 8*n_batches doubles to out_host). */
+int sps_metrics(sps_ctx *ctx, const float *scores_dev, const float *batch_dev, int64_t ld, int64_t n,
+                float eps, int n_batches, double *out_host, void *stream);
+
+/* ---- variant-B submap (online path) ---------------------------------------------------
+ * Replaces util.to_coords_features + util.prune (reference util.py:67-114): voxel =
+ * trunc(xyz / ds) in f32; the map's unique voxel set is kept in a device-resident hash
+ * (the reference rebuilds it every callback, util.py:86-89). */
+int sps_map_upload(sps_ctx *ctx, const float *map_xyz_dev, int64_t ld, int64_t m, float ds, void *stream);
+/* Same, from int32 voxel indices [m,3] already produced by util.to_coords_features
+ * (reference util.py:75: (xyz/ds).int()), row stride ld ints. */
+int sps_map_upload_voxels(sps_ctx *ctx, const int32_t *map_ijk_dev, int64_t ld, int64_t m, void *stream);
+/* out_xyz_dev must hold n rows of 3 floats.  Writes the voxel corners (ix*ds, f32) of
+ * (unique scan voxels INTERSECT map voxels) in scan first-occurrence order.
+ * Synchronises; *n_sub = rows written, *n_scan_vox = number of unique scan voxels.
+ * The float form truncates xyz/ds itself with the ds given to sps_map_upload. */
+int sps_submap_voxel(sps_ctx *ctx, const float *scan_xyz_dev, int64_t ld, int64_t n, float *out_xyz_dev,
+                     int64_t *n_sub, int64_t *n_scan_vox, void *stream);
+int sps_submap_voxel_ijk(sps_ctx *ctx, const int32_t *scan_ijk_dev, int64_t ld, int64_t n, float ds,
+                         float *out_xyz_dev, int64_t *n_sub, int64_t *n_scan_vox, void *stream);
+
+/* ---- introspection (parity tests; all synchronise) ----------------------------------- */
+/* Number of active voxels at each tensor stride of the last forward. */
+int sps_level_counts(sps_ctx *ctx, int64_t counts_host[SPS_NUM_LEVELS]);
+/* Integer coordinates [V,5] (b,x,y,z,t) of level `level` (0 = tensor stride 1). */
+int sps_get_voxels(sps_ctx *ctx, int level, int32_t *coords_dev);
+/* inverse map point -> ts1 voxel row, int64 [n] (-1 for out-of-range rows). */
+int sps_get_inverse(sps_ctx *ctx, int64_t *inv_dev);
+/* parent row (level+1) of each voxel of `level` (0..3), int32 [V_level]. */
+int sps_get_parent(sps_ctx *ctx, int level, int32_t *parent_dev);
+/* Kernel-map pair counts: which = 0..4 -> 3x3x3x3 map at level which; 5 -> 5x5x5x1 map at
+ * level 0.  pairs_host[k] = number of (in,out) pairs of offset k (81 or 125 entries). */
+int sps_get_map_pairs(sps_ctx *ctx, int which, int64_t *pairs_host);
+/* Per-voxel logits of the last forward, float32 [V_0]. */
+int sps_get_logits(sps_ctx *ctx, float *logits_dev);
+/* Named intermediate feature maps: "out_p1","block1".."block8"; copies [V,C] row-major
+ * f32 (compact, ld = C) into out_dev; *rows,*cols describe it. */
+int sps_get_feature(sps_ctx *ctx, const char *name, float *out_dev, int64_t *rows, int64_t *cols);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPS_HIP_H */

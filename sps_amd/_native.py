@@ -1,0 +1,148 @@
+"""ctypes binding of libsps_hip.so (C ABI: include/sps_hip.h).
+
+The product path has NO fallback: if the library is missing or fails to load, importing
+this module raises.  Device pointers are passed as integers (``tensor.data_ptr()``)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+NUM_LEVELS = 5
+SPS_OK = 0
+ERR_RANGE = -4
+
+
+class SpsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libsps_hip error {code}: {msg}")
+        self.code = code
+
+
+def _load() -> C.CDLL:
+    path = _build.LIB
+    if not os.path.exists(path):
+        # building needs only hipcc (cross-compiles without a GPU); never falls back to CPU code
+        path = _build.build()
+    lib = C.CDLL(path)
+    vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+    sig = {
+        "sps_last_error": (C.c_char_p, []),
+        "sps_version": (i32, []),
+        "sps_ctx_create": (i32, [i32, C.POINTER(vp)]),
+        "sps_ctx_destroy": (i32, [vp]),
+        "sps_reserve": (i32, [vp, i64]),
+        "sps_weights_num_tensors": (i32, []),
+        "sps_weights_tensor_info": (i32, [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
+        "sps_weights_numel": (i64, []),
+        "sps_weights_load": (i32, [vp, vp, i64]),
+        "sps_forward": (i32, [vp, vp, i64, i64, f32, vp, vp]),
+        "sps_check": (i32, [vp, vp]),
+        "sps_metrics": (i32, [vp, vp, vp, i64, i64, f32, i32, C.POINTER(C.c_double), vp]),
+        "sps_map_upload": (i32, [vp, vp, i64, i64, f32, vp]),
+        "sps_map_upload_voxels": (i32, [vp, vp, i64, i64, vp]),
+        "sps_submap_voxel": (i32, [vp, vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp]),
+        "sps_submap_voxel_ijk": (i32, [vp, vp, i64, i64, f32, vp, C.POINTER(i64), C.POINTER(i64), vp]),
+        "sps_level_counts": (i32, [vp, C.POINTER(i64)]),
+        "sps_get_voxels": (i32, [vp, i32, vp]),
+        "sps_get_inverse": (i32, [vp, vp]),
+        "sps_get_parent": (i32, [vp, i32, vp]),
+        "sps_get_map_pairs": (i32, [vp, i32, C.POINTER(i64)]),
+        "sps_get_logits": (i32, [vp, vp]),
+        "sps_get_feature": (i32, [vp, C.c_char_p, vp, C.POINTER(i64), C.POINTER(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
+           "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
+           "sps_forward", "sps_check", "sps_metrics", "sps_map_upload", "sps_map_upload_voxels",
+           "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_level_counts", "sps_get_voxels",
+           "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_logits", "sps_get_feature"]
+
+
+def check(rc: int) -> None:
+    if rc != SPS_OK:
+        raise SpsError(rc, lib.sps_last_error().decode())
+
+
+def weight_layout():
+    """[(name, offset, numel)] of the weight blob, from the library itself."""
+    out = []
+    buf = C.create_string_buffer(128)
+    off, num = C.c_int64(), C.c_int64()
+    for i in range(lib.sps_weights_num_tensors()):
+        check(lib.sps_weights_tensor_info(i, buf, 128, C.byref(off), C.byref(num)))
+        out.append((buf.value.decode(), off.value, num.value))
+    return out
+
+
+class Context:
+    """Owns one ``sps_ctx`` (one per process and device)."""
+
+    def __init__(self, device: int = 0):
+        h = C.c_void_p()
+        check(lib.sps_ctx_create(device, C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.sps_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- thin wrappers ----------------------------------------------------------------
+    def reserve(self, max_points: int):
+        check(lib.sps_reserve(self.handle, int(max_points)))
+
+    def load_weights(self, blob_host_ptr: int, numel: int):
+        check(lib.sps_weights_load(self.handle, blob_host_ptr, int(numel)))
+
+    def forward(self, coords_ptr: int, ld: int, n: int, voxel_size: float, scores_ptr: int, stream: int):
+        check(lib.sps_forward(self.handle, coords_ptr, ld, n, voxel_size, scores_ptr, stream))
+
+    def check_errors(self, stream: int):
+        check(lib.sps_check(self.handle, stream))
+
+    def metrics(self, scores_ptr: int, batch_ptr: int, ld: int, n: int, eps: float, n_batches: int, stream: int):
+        out = (C.c_double * (8 * n_batches))()
+        check(lib.sps_metrics(self.handle, scores_ptr, batch_ptr, ld, n, eps, n_batches, out, stream))
+        return [list(out[8 * b: 8 * b + 8]) for b in range(n_batches)]
+
+    def map_upload(self, xyz_ptr: int, ld: int, m: int, ds: float, stream: int):
+        check(lib.sps_map_upload(self.handle, xyz_ptr, ld, m, ds, stream))
+
+    def map_upload_voxels(self, ijk_ptr: int, ld: int, m: int, stream: int):
+        check(lib.sps_map_upload_voxels(self.handle, ijk_ptr, ld, m, stream))
+
+    def submap_voxel(self, scan_ptr: int, ld: int, n: int, out_ptr: int, stream: int):
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.sps_submap_voxel(self.handle, scan_ptr, ld, n, out_ptr, C.byref(a), C.byref(b), stream))
+        return a.value, b.value
+
+    def submap_voxel_ijk(self, scan_ptr: int, ld: int, n: int, ds: float, out_ptr: int, stream: int):
+        a, b = C.c_int64(), C.c_int64()
+        check(lib.sps_submap_voxel_ijk(self.handle, scan_ptr, ld, n, ds, out_ptr, C.byref(a), C.byref(b), stream))
+        return a.value, b.value
+
+    def level_counts(self):
+        out = (C.c_int64 * NUM_LEVELS)()
+        check(lib.sps_level_counts(self.handle, out))
+        return list(out)
+
+    def map_pairs(self, which: int):
+        out = (C.c_int64 * 125)()
+        check(lib.sps_get_map_pairs(self.handle, which, out))
+        return list(out)[: 125 if which == 5 else 81]

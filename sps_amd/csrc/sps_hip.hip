@@ -1,0 +1,1385 @@
+// sps_hip.hip -- MI355X (gfx950 / CDNA4) native implementation of the SPS per-scan hot path.
+// C ABI: include/sps_hip.h.  Written for gfx950 only: 64-lane wavefronts, f32 MFMA
+// (v_mfma_f32_16x16x4_f32), no compatibility layers.
+//
+// Path implemented (reference file:line it replaces):
+//   quantise + floor + unique voxels + inverse map   src/sps/models/models.py:21-25 (ME TensorField.sparse)
+//   stride-2 coordinate pyramid, kernel maps          ME CoordinateMapManager (minkunet.py:162-217 triggers)
+//   33 sparse convolutions + eval BN + ReLU + residual + concat   minkunet.py:161-219, resnet.py:96-126
+//   slice + sigmoid                                   models.py:28-29
+//   per-scan confusion counts / MSE / R2 sums         models.py:84-105, util.py:285-299
+//   variant-B submap (device-resident map hash)       util.py:67-114
+//
+// Data layout in HBM
+//   voxel key   : u64  [b:5 | t+16:5 | z+2^17:18 | y+2^17:18 | x+2^17:18]
+//   hash table  : open addressing, linear probing, load <= 0.5: keys u64[cap], first i32[cap], rank i32[cap]
+//   kernel map  : output-stationary neighbour table  nbr[k][v] (k-major, row stride = arena capacity), -1 = absent
+//   features    : row-major f32 [V, C]; concatenations are strided views of one buffer (ME.cat costs nothing)
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sps_hip.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess) return fail(SPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// voxel keys
+// ------------------------------------------------------------------------------------------
+constexpr uint64_t KEY_EMPTY = ~0ull;
+constexpr int XB = 18;
+constexpr int XBIAS = 1 << (XB - 1);
+constexpr int TBIAS = 16;
+
+__host__ __device__ inline bool key_in_range(int b, int x, int y, int z, int t) {
+  return b >= 0 && b <= SPS_BATCH_MAX && t >= SPS_T_MIN && t <= SPS_T_MAX && x >= SPS_COORD_MIN &&
+         x <= SPS_COORD_MAX && y >= SPS_COORD_MIN && y <= SPS_COORD_MAX && z >= SPS_COORD_MIN &&
+         z <= SPS_COORD_MAX;
+}
+__host__ __device__ inline uint64_t key_pack(int b, int x, int y, int z, int t) {
+  return ((uint64_t)b << 59) | ((uint64_t)(t + TBIAS) << 54) | ((uint64_t)(z + XBIAS) << 36) |
+         ((uint64_t)(y + XBIAS) << 18) | (uint64_t)(x + XBIAS);
+}
+__host__ __device__ inline void key_unpack(uint64_t k, int &b, int &x, int &y, int &z, int &t) {
+  x = (int)(k & 0x3FFFF) - XBIAS;
+  y = (int)((k >> 18) & 0x3FFFF) - XBIAS;
+  z = (int)((k >> 36) & 0x3FFFF) - XBIAS;
+  t = (int)((k >> 54) & 0x1F) - TBIAS;
+  b = (int)(k >> 59);
+}
+// floor(c / 2ts) * 2ts on x,y,z: the bias is a multiple of 2ts, so it is a mask of the low bits.
+__device__ inline uint64_t key_parent(uint64_t k, int ts) {
+  const uint64_t m = (uint64_t)(2 * ts - 1);
+  return k & ~(m | (m << 18) | (m << 36));
+}
+
+__device__ inline uint32_t hash64(uint64_t k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdULL;
+  k ^= k >> 33;
+  k *= 0xc4ceb9fe1a85ec53ULL;
+  k ^= k >> 33;
+  return (uint32_t)k;
+}
+
+struct HashTable {
+  uint64_t *keys;
+  int *first;  // smallest source index that inserted the key (first occurrence)
+  int *rank;   // voxel row of the key (first-occurrence order)
+  uint32_t mask;
+};
+
+__device__ inline int hash_insert(const HashTable &h, uint64_t key) {
+  uint32_t s = hash64(key) & h.mask;
+  while (true) {
+    unsigned long long prev =
+        atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[s]), (unsigned long long)KEY_EMPTY,
+                  (unsigned long long)key);
+    if (prev == KEY_EMPTY || prev == key) return (int)s;
+    s = (s + 1) & h.mask;
+  }
+}
+__device__ inline int hash_find_slot(const HashTable &h, uint64_t key) {
+  uint32_t s = hash64(key) & h.mask;
+  while (true) {
+    const uint64_t k = h.keys[s];
+    if (k == key) return (int)s;
+    if (k == KEY_EMPTY) return -1;
+    s = (s + 1) & h.mask;
+  }
+}
+__device__ inline int hash_lookup(const HashTable &h, uint64_t key) {
+  const int s = hash_find_slot(h, key);
+  return s < 0 ? -1 : h.rank[s];
+}
+
+// ------------------------------------------------------------------------------------------
+// voxelisation kernels
+// ------------------------------------------------------------------------------------------
+constexpr int SCAN_BLOCK = 1024;
+
+// level 0: quantise points (models.py:21: f32 true division by [1,vs,vs,vs,1]; ME floor) and insert.
+__global__ void k_points_insert(const float *__restrict__ coords, int64_t ld, int n, float vs, HashTable h,
+                                uint64_t *__restrict__ srckey, int *__restrict__ pslot, int *err) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float *c = coords + (size_t)p * ld;
+  const float fb = floorf(__fdiv_rn(c[0], 1.0f));
+  const float fx = floorf(__fdiv_rn(c[1], vs));
+  const float fy = floorf(__fdiv_rn(c[2], vs));
+  const float fz = floorf(__fdiv_rn(c[3], vs));
+  const float ft = floorf(__fdiv_rn(c[4], 1.0f));
+  // compare in float first so that huge / NaN values cannot overflow the int conversion
+  const bool ok = fb >= 0.f && fb <= (float)SPS_BATCH_MAX && ft >= (float)SPS_T_MIN && ft <= (float)SPS_T_MAX &&
+                  fx >= (float)SPS_COORD_MIN && fx <= (float)SPS_COORD_MAX && fy >= (float)SPS_COORD_MIN &&
+                  fy <= (float)SPS_COORD_MAX && fz >= (float)SPS_COORD_MIN && fz <= (float)SPS_COORD_MAX;
+  if (!ok) {
+    atomicOr(err, 1);
+    srckey[p] = KEY_EMPTY;
+    pslot[p] = -1;
+    return;
+  }
+  const uint64_t key = key_pack((int)fb, (int)fx, (int)fy, (int)fz, (int)ft);
+  const int s = hash_insert(h, key);
+  atomicMin(&h.first[s], p);
+  srckey[p] = key;
+  pslot[p] = s;
+}
+
+// level l >= 1: parents of the finer level's voxels (App. A.9).
+__global__ void k_parent_insert(const uint64_t *__restrict__ fine_keys, const int *__restrict__ n_fine, int ts,
+                                HashTable h, uint64_t *__restrict__ srckey, int *__restrict__ pslot) {
+  const int n = *n_fine;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const uint64_t key = key_parent(fine_keys[v], ts);
+    const int s = hash_insert(h, key);
+    atomicMin(&h.first[s], v);
+    srckey[v] = key;
+    pslot[v] = s;
+  }
+}
+
+__device__ inline int block_reduce_sum(int v, int *lds) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  int tot = 0;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) tot += lds[i];
+  __syncthreads();
+  return tot;
+}
+
+// pass A: number of first occurrences per block of SCAN_BLOCK source elements.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(const int *__restrict__ pslot, const int *first,
+                                                             const int *__restrict__ n_ptr, int n_fixed,
+                                                             int *__restrict__ block_sums) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  const int n = n_ptr ? *n_ptr : n_fixed;
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int flag = 0;
+  if (p < n) {
+    const int s = pslot[p];
+    flag = (s >= 0 && first[s] == p) ? 1 : 0;
+  }
+  const int tot = block_reduce_sum(flag, lds);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+// pass B: exclusive scan of the first-occurrence flags -> voxel rows in first-occurrence order.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(const int *__restrict__ pslot, const int *first,
+                                                            const uint64_t *__restrict__ srckey,
+                                                            const int *__restrict__ n_ptr, int n_fixed,
+                                                            const int *__restrict__ block_sums, int *rank,
+                                                            uint64_t *__restrict__ vkeys, int *__restrict__ count_out) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int wave_off[SCAN_BLOCK / 64];
+  const int n = n_ptr ? *n_ptr : n_fixed;
+  const int nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  if ((int)blockIdx.x >= nblocks) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = 0;  // n == 0
+    return;
+  }
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) part += block_sums[i];
+  const int base = block_reduce_sum(part, lds);
+
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int s = -1, flag = 0;
+  if (p < n) {
+    s = pslot[p];
+    flag = (s >= 0 && first[s] == p) ? 1 : 0;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_off[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+    const int c = wave_off[i];
+    if (i < wave) off += c;
+    tot += c;
+  }
+  if (flag) {
+    const int r = base + off + in_wave;
+    rank[s] = r;
+    vkeys[r] = srckey[p];
+  }
+  if ((int)blockIdx.x == nblocks - 1 && threadIdx.x == 0) *count_out = base + tot;
+}
+
+// pass C: source element -> voxel row (inverse map for level 0, parent row for levels >= 1).
+__global__ void k_source_to_row(const int *__restrict__ pslot, const int *__restrict__ rank,
+                                const int *__restrict__ n_ptr, int n_fixed, int *__restrict__ inv) {
+  const int n = n_ptr ? *n_ptr : n_fixed;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const int s = pslot[p];
+    inv[p] = s >= 0 ? rank[s] : -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel maps (output-stationary neighbour tables)
+// ------------------------------------------------------------------------------------------
+enum NbrKind { NBR_3333 = 0, NBR_5551 = 1, NBR_DOWN = 2 };
+
+// nbr[k*ldn + u] = row (in the `in` table) of coordinate out_key[u] + offset_k, or -1  (App. A.6-A.8).
+//   NBR_3333 : k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1), spatial offsets * ts
+//   NBR_5551 : k = (dx+2) + 5(dy+2) + 25(dz+2)
+//   NBR_DOWN : k = dx + 2dy + 4dz, d in {0,1} * ts (ts = stride of the INPUT = finer level)
+template <int KIND>
+__global__ void k_build_nbr(const uint64_t *__restrict__ out_keys, const int *__restrict__ n_out, int ts,
+                            HashTable in, int *__restrict__ nbr, int64_t ldn) {
+  const int n = *n_out;
+  const int k = blockIdx.y;
+  int dx, dy, dz, dt = 0;
+  if (KIND == NBR_3333) {
+    dx = (k % 3 - 1) * ts;
+    dy = ((k / 3) % 3 - 1) * ts;
+    dz = ((k / 9) % 3 - 1) * ts;
+    dt = k / 27 - 1;
+  } else if (KIND == NBR_5551) {
+    dx = (k % 5 - 2) * ts;
+    dy = ((k / 5) % 5 - 2) * ts;
+    dz = (k / 25 - 2) * ts;
+  } else {
+    dx = (k & 1) * ts;
+    dy = ((k >> 1) & 1) * ts;
+    dz = ((k >> 2) & 1) * ts;
+  }
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    int b, x, y, z, t;
+    key_unpack(out_keys[u], b, x, y, z, t);
+    x += dx;
+    y += dy;
+    z += dz;
+    t += dt;
+    int r = -1;
+    if (key_in_range(b, x, y, z, t)) r = hash_lookup(in, key_pack(b, x, y, z, t));
+    nbr[(size_t)k * ldn + u] = r;
+  }
+}
+
+// transposed conv map (App. A.10): fine voxel v receives exactly one term, from its parent, through
+// offset k = octant of v inside the parent:  up[k*ldn + v] = (k == oct(v)) ? parent[v] : -1.
+__global__ void k_build_up(const uint64_t *__restrict__ fine_keys, const int *__restrict__ n_fine, int ts,
+                           const int *__restrict__ parent, int *__restrict__ up, int64_t ldn) {
+  const int n = *n_fine;
+  int sh = 0;
+  while ((1 << sh) < ts) ++sh;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
+    const uint64_t key = fine_keys[v];
+    const int oct = (int)((key >> sh) & 1) | ((int)((key >> (18 + sh)) & 1) << 1) | ((int)((key >> (36 + sh)) & 1) << 2);
+    const int par = parent[v];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) up[(size_t)k * ldn + v] = (k == oct) ? par : -1;
+  }
+}
+
+__global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, const int *__restrict__ n_ptr,
+                              unsigned long long *__restrict__ pairs) {
+  const int n = *n_ptr;
+  const int k = blockIdx.y;
+  int c = 0;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
+    c += nbr[(size_t)k * ldn + u] >= 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pairs[k], (unsigned long long)c);
+}
+
+// ------------------------------------------------------------------------------------------
+// sparse convolution: output-stationary gather + f32 MFMA, fused BN / residual / ReLU epilogue
+// ------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float *in;     // [*, ldi]
+  float *out;          // [*, ldo]
+  const float *W;      // [K*cin, cout] (= [K][cin][cout] flattened)
+  const float *scale;  // [cout]  folded BN (or 1)
+  const float *shift;  // [cout]  folded BN (or bias)
+  const float *res;    // residual [*, ldr] or null
+  const int *nbr;      // [K][ldn] or null (identity, K == 1)
+  const int *n_out;    // device count of output rows
+  int64_t ldn;
+  int ldi, ldo, ldr;
+  int K, cin, cout;
+  int relu;
+  float in_const;  // cin == 1: constant input feature (0.5, models.py:22) when in == null
+};
+
+// One wave = 16 output rows x (NT*16) output channels.  The GEMM K dimension is the flattened
+// (offset k, input channel) index j = k*cin + ci, i.e. W viewed as [K*cin][cout]; A[row][j] is the
+// gathered input feature (0 when the neighbour is absent).  v_mfma_f32_16x16x4_f32 lane map
+// (cdna_hip_programming.md section 3): lane l holds A[l&15][l>>4] and B[l>>4][l&15]; each lane
+// loads one float4 (4 consecutive ci of "unit" u = 4g + (l>>4)) and feeds it over 4 MFMA steps, so
+// that step s multiplies A[.][j = 4u+s] by B[j = 4u+s][.] -- a permutation of the K order inside a
+// group of 16, which a sum does not see.  Groups whose 16 rows have no present neighbour are skipped.
+template <int NT>
+__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+  const int count = *a.n_out;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int upk = a.cin >> 2;
+  const int total_units = a.K * upk;
+  const int groups = (total_units + 3) >> 2;
+  for (int tile = blockIdx.x; tile * 64 < count; tile += gridDim.x) {
+    const int row0 = tile * 64 + wave * 16;
+    if (row0 >= count) continue;
+    const int row = row0 + r;
+    const bool rvalid = row < count;
+    floatx4 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    for (int g = 0; g < groups; ++g) {
+      const int u = 4 * g + q;
+      const bool uvalid = u < total_units;
+      int idx = -1, c4 = 0;
+      if (rvalid && uvalid) {
+        const int k = u / upk;
+        c4 = u - k * upk;
+        idx = a.nbr ? a.nbr[(size_t)k * a.ldn + row] : row;
+      }
+      if (__ballot(idx >= 0) == 0ull) continue;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx >= 0) v = *reinterpret_cast<const float4 *>(a.in + (size_t)idx * a.ldi + 4 * c4);
+      const float av[4] = {v.x, v.y, v.z, v.w};
+      const float *wrow = a.W + (size_t)(4 * u) * a.cout;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int col = nt * 16 + r;
+          const float bv = (uvalid && col < a.cout) ? wrow[s * a.cout + col] : 0.f;
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col = nt * 16 + r;
+      if (col >= a.cout) continue;
+      const float sc = a.scale[col], sh = a.shift[col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        if (ro >= count) continue;
+        float y = acc[nt][i] * sc + sh;
+        if (a.res) y += a.res[(size_t)ro * a.ldr + col];
+        if (a.relu) y = fmaxf(y, 0.f);
+        a.out[(size_t)ro * a.ldo + col] = y;
+      }
+    }
+  }
+}
+
+// cin == 1 (conv0p1s1, 5x5x5x1): the GEMM K dimension is the kernel offset itself.
+__global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
+  const int count = *a.n_out;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int groups = (a.K + 3) >> 2;
+  for (int tile = blockIdx.x; tile * 64 < count; tile += gridDim.x) {
+    const int row0 = tile * 64 + wave * 16;
+    if (row0 >= count) continue;
+    const int row = row0 + r;
+    const bool rvalid = row < count;
+    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int g = 0; g < groups; ++g) {
+      const int k = 4 * g + q;
+      const bool kvalid = k < a.K;
+      int idx = -1;
+      if (rvalid && kvalid) idx = a.nbr ? a.nbr[(size_t)k * a.ldn + row] : row;
+      if (__ballot(idx >= 0) == 0ull) continue;
+      float av = 0.f;
+      if (idx >= 0) av = a.in ? a.in[(size_t)idx * a.ldi] : a.in_const;
+      const float bv = (kvalid && r < a.cout) ? a.W[(size_t)k * a.cout + r] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (r < a.cout) {
+      const float sc = a.scale[r], sh = a.shift[r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        if (ro >= count) continue;
+        float y = acc[i] * sc + sh;
+        if (a.res) y += a.res[(size_t)ro * a.ldr + r];
+        if (a.relu) y = fmaxf(y, 0.f);
+        a.out[(size_t)ro * a.ldo + r] = y;
+      }
+    }
+  }
+}
+
+// slice (models.py:28) + sigmoid (models.py:29)
+__global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__restrict__ inv, int n,
+                                float *__restrict__ scores) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = inv[p];
+  scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
+}
+
+// ------------------------------------------------------------------------------------------
+// metrics (models.py:84-105, util.py:285-299): per batch index accumulators over scan rows
+// ------------------------------------------------------------------------------------------
+__global__ void k_metrics(const float *__restrict__ scores, const float *__restrict__ batch, int64_t ld, int n,
+                          float eps, int n_batches, double *__restrict__ acc) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int b = -1;
+  if (p < n) {
+    const float *row = batch + (size_t)p * ld;
+    if (row[4] == 1.0f) {
+      const int bi = (int)row[0];
+      if (bi >= 0 && bi < n_batches) {
+        b = bi;
+        const float s = scores[p], g = row[5];
+        const int pred = s < eps ? 0 : 1, gt = g < eps ? 0 : 1;
+        const double d = (double)s - (double)g;
+        v[0] = 1;
+        v[1] = (gt == 1 && pred == 1);
+        v[2] = (gt == 0 && pred == 1);
+        v[3] = (gt == 1 && pred == 0);
+        v[4] = (gt == 0 && pred == 0);
+        v[5] = d * d;
+        v[6] = g;
+        v[7] = (double)g * (double)g;
+      }
+    }
+  }
+  // wave-level reduction when every contributing lane shares one batch index (the common case)
+  int bref = b;
+  for (int o = 32; o > 0; o >>= 1) bref = max(bref, __shfl_xor(bref, o, 64));
+  if (bref < 0) return;  // wave-uniform
+  if (__all(b == bref || b < 0)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double x = v[j];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+      if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(&acc[bref * 8 + j], x);
+    }
+  } else if (b >= 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (v[j] != 0.0) atomicAdd(&acc[b * 8 + j], v[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// variant-B submap (util.py:67-114): trunc grid, map hash resident on the device
+// ------------------------------------------------------------------------------------------
+__device__ inline bool trunc_key(const float *c, float ds, uint64_t &key) {
+  // torch: (xyz / ds).int() -> f32 division, truncation toward zero
+  const float fx = truncf(__fdiv_rn(c[0], ds)), fy = truncf(__fdiv_rn(c[1], ds)), fz = truncf(__fdiv_rn(c[2], ds));
+  const bool ok = fx >= (float)SPS_COORD_MIN && fx <= (float)SPS_COORD_MAX && fy >= (float)SPS_COORD_MIN &&
+                  fy <= (float)SPS_COORD_MAX && fz >= (float)SPS_COORD_MIN && fz <= (float)SPS_COORD_MAX;
+  if (!ok) return false;
+  key = key_pack(0, (int)fx, (int)fy, (int)fz, 0);
+  return true;
+}
+
+__device__ inline bool ijk_key(const int32_t *c, uint64_t &key) {
+  if (!key_in_range(0, c[0], c[1], c[2], 0)) return false;
+  key = key_pack(0, c[0], c[1], c[2], 0);
+  return true;
+}
+
+// IJK = false: rows are float xyz (truncated here); IJK = true: rows are int32 voxel indices
+// (already truncated by util.to_coords_features).
+template <bool IJK>
+__global__ void k_map_insert(const void *__restrict__ src, int64_t ld, int64_t m, float ds, HashTable h, int *err) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  uint64_t key;
+  const bool ok = IJK ? ijk_key((const int32_t *)src + (size_t)p * ld, key)
+                      : trunc_key((const float *)src + (size_t)p * ld, ds, key);
+  if (!ok) {
+    atomicOr(err, 1);
+    return;
+  }
+  hash_insert(h, key);
+}
+
+template <bool IJK>
+__global__ void k_scan_trunc_insert(const void *__restrict__ src, int64_t ld, int n, float ds, HashTable h,
+                                    uint64_t *__restrict__ srckey, int *__restrict__ pslot, int *err) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint64_t key;
+  const bool ok = IJK ? ijk_key((const int32_t *)src + (size_t)p * ld, key)
+                      : trunc_key((const float *)src + (size_t)p * ld, ds, key);
+  if (!ok) {
+    atomicOr(err, 1);
+    srckey[p] = KEY_EMPTY;
+    pslot[p] = -1;
+    return;
+  }
+  const int s = hash_insert(h, key);
+  atomicMin(&h.first[s], p);
+  srckey[p] = key;
+  pslot[p] = s;
+}
+
+// After the first-occurrence pass: keep the unique scan voxels that exist in the map hash.
+// Turns pslot into -1 for non-first / non-hit points so that the generic count/rank passes compact
+// exactly the intersection, in scan first-occurrence order.  counts[0] += number of unique scan voxels.
+__global__ void k_submap_filter(int *__restrict__ pslot, const int *first, const uint64_t *__restrict__ srckey, int n,
+                                HashTable map, int *__restrict__ keep, int *__restrict__ n_scan_vox) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int uniq = 0, k = 0;
+  if (p < n) {
+    const int s = pslot[p];
+    if (s >= 0 && first[s] == p) {
+      uniq = 1;
+      k = hash_find_slot(map, srckey[p]) >= 0;
+    }
+    keep[p] = k;
+  }
+  const unsigned long long bal = __ballot(uniq);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_scan_vox, __popcll(bal));
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_keep_count(const int *__restrict__ keep, int n,
+                                                            int *__restrict__ block_sums) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int flag = p < n ? keep[p] : 0;
+  const int tot = block_reduce_sum(flag, lds);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_keep_write(const int *__restrict__ keep,
+                                                            const uint64_t *__restrict__ srckey, int n, float ds,
+                                                            const int *__restrict__ block_sums,
+                                                            float *__restrict__ out_xyz, int *__restrict__ count_out) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int wave_off[SCAN_BLOCK / 64];
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) part += block_sums[i];
+  const int base = block_reduce_sum(part, lds);
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int flag = p < n ? keep[p] : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_off[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+    const int c = wave_off[i];
+    if (i < wave) off += c;
+    tot += c;
+  }
+  if (flag) {
+    int b, x, y, z, t;
+    key_unpack(srckey[p], b, x, y, z, t);
+    float *o = out_xyz + (size_t)(base + off + in_wave) * 3;
+    // torch: int32 tensor * python float -> float32 (util.py:112)
+    o[0] = (float)x * ds;
+    o[1] = (float)y * ds;
+    o[2] = (float)z * ds;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_out = base + tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------
+__global__ void k_keys_to_coords(const uint64_t *__restrict__ keys, int n, int32_t *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  int b, x, y, z, t;
+  key_unpack(keys[v], b, x, y, z, t);
+  int32_t *o = out + (size_t)v * 5;
+  o[0] = b;
+  o[1] = x;
+  o[2] = y;
+  o[3] = z;
+  o[4] = t;
+}
+__global__ void k_i32_to_i64(const int *__restrict__ in, int n, int64_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void k_copy_strided(const float *__restrict__ in, int ldi, int rows, int cols, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  out[i] = in[(size_t)r * ldi + c];
+}
+
+// ------------------------------------------------------------------------------------------
+// network description (CustomMinkUNet = MinkUNet14 wiring, customminkunet.py:10-12)
+// ------------------------------------------------------------------------------------------
+constexpr int PLANES[8] = {8, 16, 32, 64, 64, 32, 16, 8};
+constexpr int INIT_DIM = 8;
+
+struct ConvSpec {
+  std::string name;  // state_dict name without ".kernel"
+  std::string bn;    // BN that follows ("" for final)
+  int K, cin, cout;
+  int64_t w_off = 0;   // offset of the kernel in the blob (floats)
+  int64_t ss_off = 0;  // offset of scale/shift pair in the derived buffer
+};
+struct BnSpec {
+  std::string name;
+  int c;
+  int64_t off = 0;  // weight, bias, running_mean, running_var consecutively
+};
+struct TensorInfo {
+  std::string name;
+  int64_t off, numel;
+};
+
+struct NetSpec {
+  std::vector<ConvSpec> convs;
+  std::vector<BnSpec> bns;
+  std::vector<TensorInfo> tensors;
+  int64_t numel = 0, ss_numel = 0, bias_off = 0;
+  int find_conv(const std::string &n) const {
+    for (size_t i = 0; i < convs.size(); ++i)
+      if (convs[i].name == n) return (int)i;
+    return -1;
+  }
+  int find_bn(const std::string &n) const {
+    for (size_t i = 0; i < bns.size(); ++i)
+      if (bns[i].name == n) return (int)i;
+    return -1;
+  }
+};
+
+void add_block(NetSpec &s, const std::string &name, int cin, int cout) {
+  s.convs.push_back({name + ".0.conv1", name + ".0.norm1", 81, cin, cout});
+  s.convs.push_back({name + ".0.conv2", name + ".0.norm2", 81, cout, cout});
+  s.bns.push_back({name + ".0.norm1", cout});
+  s.bns.push_back({name + ".0.norm2", cout});
+  if (cin != cout) {  // resnet.py:98
+    s.convs.push_back({name + ".0.downsample.0", name + ".0.downsample.1", 1, cin, cout});
+    s.bns.push_back({name + ".0.downsample.1", cout});
+  }
+}
+
+NetSpec build_spec() {
+  NetSpec s;
+  s.convs.push_back({"conv0p1s1", "bn0", 125, 1, INIT_DIM});
+  s.bns.push_back({"bn0", INIT_DIM});
+  const char *downs[4] = {"conv1p1s2", "conv2p2s2", "conv3p4s2", "conv4p8s2"};
+  int cur = INIT_DIM;
+  for (int i = 0; i < 4; ++i) {
+    s.convs.push_back({downs[i], "bn" + std::to_string(i + 1), 8, cur, cur});
+    s.bns.push_back({"bn" + std::to_string(i + 1), cur});
+    add_block(s, "block" + std::to_string(i + 1), cur, PLANES[i]);
+    cur = PLANES[i];
+  }
+  const char *ups[4] = {"convtr4p16s2", "convtr5p8s2", "convtr6p4s2", "convtr7p2s2"};
+  const int skip[4] = {PLANES[2], PLANES[1], PLANES[0], INIT_DIM};
+  for (int i = 0; i < 4; ++i) {
+    s.convs.push_back({ups[i], "bntr" + std::to_string(4 + i), 8, cur, PLANES[4 + i]});
+    s.bns.push_back({"bntr" + std::to_string(4 + i), PLANES[4 + i]});
+    add_block(s, "block" + std::to_string(5 + i), PLANES[4 + i] + skip[i], PLANES[4 + i]);
+    cur = PLANES[4 + i];
+  }
+  s.convs.push_back({"final", "", 1, PLANES[7], 1});
+  // blob layout: conv kernels, then BN (weight,bias,mean,var), then final.bias
+  int64_t off = 0, ss = 0;
+  for (auto &c : s.convs) {
+    c.w_off = off;
+    const int64_t n = (int64_t)c.K * c.cin * c.cout;
+    s.tensors.push_back({c.name + ".kernel", off, n});
+    off += n;
+    c.ss_off = ss;
+    ss += 2 * c.cout;
+  }
+  const char *bn_parts[4] = {".bn.weight", ".bn.bias", ".bn.running_mean", ".bn.running_var"};
+  for (auto &b : s.bns) {
+    b.off = off;
+    for (int j = 0; j < 4; ++j) {
+      s.tensors.push_back({b.name + bn_parts[j], off, b.c});
+      off += b.c;
+    }
+  }
+  s.bias_off = off;
+  s.tensors.push_back({"final.bias", off, 1});
+  off += 1;
+  s.numel = off;
+  s.ss_numel = ss;
+  return s;
+}
+
+const NetSpec &spec() {
+  static const NetSpec s = build_spec();
+  return s;
+}
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+inline int64_t next_pow2(int64_t v) {
+  int64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+struct Level {
+  HashTable h{};
+  uint64_t *vkeys = nullptr;   // [cap] voxel keys in row order
+  uint64_t *srckey = nullptr;  // [cap] key of each source element
+  int *pslot = nullptr;        // [cap] slot of each source element
+  int *inv = nullptr;          // [cap] source element -> row (level 0: point->voxel, else parent row)
+  int *nbr3 = nullptr;         // [81][cap]
+  int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
+  int *up = nullptr;           // [8][cap]  (levels 1..4) indexed by level-1 voxel
+};
+
+struct Feat {
+  const char *name;
+  float *ptr;
+  int ld, cols, level;
+};
+
+}  // namespace
+
+struct sps_ctx {
+  int device = 0;
+  int64_t cap = 0;       // arena capacity in rows (points)
+  int64_t hcap = 0;      // hash capacity
+  int64_t last_n = 0;    // points of the last forward
+  bool have_weights = false;
+  std::vector<void *> allocs;
+  Level lv[SPS_NUM_LEVELS];
+  int *nbr5 = nullptr;       // [125][cap]
+  int *counts = nullptr;     // device: [0..4] voxels per level, [5] submap rows, [6] scan voxels, [7] spare
+  int *err = nullptr;        // device error flag
+  int *block_sums = nullptr;
+  int *keep = nullptr;
+  double *macc = nullptr;    // metrics accumulators [32*8]
+  unsigned long long *pairs = nullptr;  // [128]
+  float *blob = nullptr;     // weights
+  float *ss = nullptr;       // folded scale/shift
+  // feature buffers
+  float *cat8 = nullptr, *b8t = nullptr, *b8r = nullptr, *b8o = nullptr, *logits = nullptr;
+  float *x1 = nullptr, *b1t = nullptr, *cat7 = nullptr, *b7t = nullptr, *b7r = nullptr, *b7o = nullptr;
+  float *x2 = nullptr, *b2t = nullptr, *b2r = nullptr, *cat6 = nullptr, *b6t = nullptr, *b6r = nullptr, *b6o = nullptr;
+  float *x3 = nullptr, *b3t = nullptr, *b3r = nullptr, *cat5 = nullptr, *b5t = nullptr, *b5r = nullptr, *b5o = nullptr;
+  float *x4 = nullptr, *b4t = nullptr, *b4r = nullptr, *b4o = nullptr;
+  // map hash (variant-B submap)
+  HashTable map{};
+  int64_t map_cap = 0;
+  float map_ds = 0.f;
+  void *map_keys_alloc = nullptr;
+};
+
+namespace {
+
+int dev_alloc(sps_ctx *c, void **p, size_t bytes) {
+  hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+  if (e != hipSuccess) return fail(SPS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  c->allocs.push_back(*p);
+  return SPS_OK;
+}
+
+void free_arena(sps_ctx *c) {
+  for (void *p : c->allocs) (void)hipFree(p);
+  c->allocs.clear();
+  c->cap = 0;
+}
+
+#define ALLOC(ptr, type, count)                                             \
+  do {                                                                      \
+    void *p_ = nullptr;                                                     \
+    int rc_ = dev_alloc(c, &p_, sizeof(type) * (size_t)(count));            \
+    if (rc_ != SPS_OK) return rc_;                                          \
+    ptr = reinterpret_cast<type *>(p_);                                     \
+  } while (0)
+
+int reserve(sps_ctx *c, int64_t n) {
+  if (n <= c->cap) return SPS_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  // weights / small state survive: they are allocated separately in ctx_create / weights_load
+  free_arena(c);
+  const int64_t cap = ((n + 1023) / 1024) * 1024;
+  const int64_t hcap = next_pow2(2 * cap);
+  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+    Level &L = c->lv[l];
+    ALLOC(L.h.keys, uint64_t, hcap);
+    ALLOC(L.h.first, int, hcap);
+    ALLOC(L.h.rank, int, hcap);
+    L.h.mask = (uint32_t)(hcap - 1);
+    ALLOC(L.vkeys, uint64_t, cap);
+    ALLOC(L.srckey, uint64_t, cap);
+    ALLOC(L.pslot, int, cap);
+    ALLOC(L.inv, int, cap);
+    ALLOC(L.nbr3, int, 81 * cap);
+    if (l > 0) {
+      ALLOC(L.down, int, 8 * cap);
+      ALLOC(L.up, int, 8 * cap);
+    }
+  }
+  ALLOC(c->nbr5, int, 125 * cap);
+  ALLOC(c->block_sums, int, cap / SCAN_BLOCK + 8);
+  ALLOC(c->keep, int, cap);
+  ALLOC(c->cat8, float, 16 * cap);
+  ALLOC(c->b8t, float, 8 * cap);
+  ALLOC(c->b8r, float, 8 * cap);
+  ALLOC(c->b8o, float, 8 * cap);
+  ALLOC(c->logits, float, cap);
+  ALLOC(c->x1, float, 8 * cap);
+  ALLOC(c->b1t, float, 8 * cap);
+  ALLOC(c->cat7, float, 24 * cap);
+  ALLOC(c->b7t, float, 16 * cap);
+  ALLOC(c->b7r, float, 16 * cap);
+  ALLOC(c->b7o, float, 16 * cap);
+  ALLOC(c->x2, float, 8 * cap);
+  ALLOC(c->b2t, float, 16 * cap);
+  ALLOC(c->b2r, float, 16 * cap);
+  ALLOC(c->cat6, float, 48 * cap);
+  ALLOC(c->b6t, float, 32 * cap);
+  ALLOC(c->b6r, float, 32 * cap);
+  ALLOC(c->b6o, float, 32 * cap);
+  ALLOC(c->x3, float, 16 * cap);
+  ALLOC(c->b3t, float, 32 * cap);
+  ALLOC(c->b3r, float, 32 * cap);
+  ALLOC(c->cat5, float, 96 * cap);
+  ALLOC(c->b5t, float, 64 * cap);
+  ALLOC(c->b5r, float, 64 * cap);
+  ALLOC(c->b5o, float, 64 * cap);
+  ALLOC(c->x4, float, 32 * cap);
+  ALLOC(c->b4t, float, 64 * cap);
+  ALLOC(c->b4r, float, 64 * cap);
+  ALLOC(c->b4o, float, 64 * cap);
+  c->cap = cap;
+  c->hcap = hcap;
+  c->last_n = 0;
+  HIP_TRY(hipMemset(c->counts, 0, 8 * sizeof(int)));
+  return SPS_OK;
+}
+
+inline int grid_for(int64_t n, int block, int maxb = 2048) {
+  int64_t g = (n + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > maxb) g = maxb;
+  return (int)g;
+}
+
+// first-occurrence compaction of the source elements of `L` (already inserted)
+int rank_level(sps_ctx *c, Level &L, const int *n_ptr, int n_fixed, int64_t n_bound, int *count_out,
+               hipStream_t st) {
+  const int nb = (int)((n_bound + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  const int nbl = nb < 1 ? 1 : nb;
+  hipLaunchKernelGGL(k_first_count, dim3(nbl), dim3(SCAN_BLOCK), 0, st, L.pslot, L.h.first, n_ptr, n_fixed,
+                     c->block_sums);
+  hipLaunchKernelGGL(k_first_rank, dim3(nbl), dim3(SCAN_BLOCK), 0, st, L.pslot, L.h.first, L.srckey, n_ptr, n_fixed,
+                     c->block_sums, L.h.rank, L.vkeys, count_out);
+  hipLaunchKernelGGL(k_source_to_row, dim3(grid_for(n_bound, 256)), dim3(256), 0, st, L.pslot, L.h.rank, n_ptr,
+                     n_fixed, L.inv);
+  return SPS_OK;
+}
+
+void launch_conv(sps_ctx *c, const ConvArgs &a, hipStream_t st) {
+  const int g = grid_for(c->cap, 64, 4096);
+  if (a.cin == 1) {
+    hipLaunchKernelGGL(k_conv_cin1, dim3(g), dim3(256), 0, st, a);
+    return;
+  }
+  const int nt = (a.cout + 15) / 16;
+  if (nt == 1)
+    hipLaunchKernelGGL(k_conv_mfma<1>, dim3(g), dim3(256), 0, st, a);
+  else if (nt == 2)
+    hipLaunchKernelGGL(k_conv_mfma<2>, dim3(g), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(k_conv_mfma<4>, dim3(g), dim3(256), 0, st, a);
+}
+
+struct ConvCall {
+  const char *name;
+  const float *in;
+  int ldi;
+  float *out;
+  int ldo;
+  const int *nbr;
+  int level_out;
+  const float *res;
+  int ldr;
+  int relu;
+};
+
+int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
+  const NetSpec &s = spec();
+  const int ci = s.find_conv(cc.name);
+  if (ci < 0) return fail(SPS_ERR_INVALID, "unknown conv %s", cc.name);
+  const ConvSpec &cs = s.convs[ci];
+  ConvArgs a{};
+  a.in = cc.in;
+  a.ldi = cc.ldi;
+  a.out = cc.out;
+  a.ldo = cc.ldo;
+  a.W = c->blob + cs.w_off;
+  a.scale = c->ss + cs.ss_off;
+  a.shift = c->ss + cs.ss_off + cs.cout;
+  a.res = cc.res;
+  a.ldr = cc.ldr;
+  a.nbr = cc.nbr;
+  a.ldn = c->cap;
+  a.n_out = c->counts + cc.level_out;
+  a.K = cs.K;
+  a.cin = cs.cin;
+  a.cout = cs.cout;
+  a.relu = cc.relu;
+  a.in_const = 0.5f;  // models.py:22
+  launch_conv(c, a, st);
+  return SPS_OK;
+}
+
+std::vector<Feat> feature_taps(sps_ctx *c) {
+  return {
+      {"out_p1", c->cat8 + 8, 16, 8, 0},  {"block1", c->cat7 + 16, 24, 8, 1}, {"block2", c->cat6 + 32, 48, 16, 2},
+      {"block3", c->cat5 + 64, 96, 32, 3}, {"block4", c->b4o, 64, 64, 4},      {"block5", c->b5o, 64, 64, 3},
+      {"block6", c->b6o, 32, 32, 2},       {"block7", c->b7o, 16, 16, 1},      {"block8", c->b8o, 8, 8, 0},
+  };
+}
+
+}  // namespace
+
+// ============================================================================================
+// C ABI
+// ============================================================================================
+extern "C" {
+
+const char *sps_last_error(void) { return g_err.c_str(); }
+int sps_version(void) { return 100; }
+
+int sps_ctx_create(int device, sps_ctx **out) {
+  if (!out) return fail(SPS_ERR_INVALID, "out is null");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(SPS_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  sps_ctx *c = new sps_ctx();
+  c->device = device;
+  const NetSpec &s = spec();
+  HIP_TRY(hipMalloc((void **)&c->counts, 8 * sizeof(int)));
+  HIP_TRY(hipMalloc((void **)&c->err, sizeof(int)));
+  HIP_TRY(hipMalloc((void **)&c->macc, 32 * 8 * sizeof(double)));
+  HIP_TRY(hipMalloc((void **)&c->pairs, 128 * sizeof(unsigned long long)));
+  HIP_TRY(hipMalloc((void **)&c->blob, s.numel * sizeof(float)));
+  HIP_TRY(hipMalloc((void **)&c->ss, s.ss_numel * sizeof(float)));
+  HIP_TRY(hipMemset(c->counts, 0, 8 * sizeof(int)));
+  HIP_TRY(hipMemset(c->err, 0, sizeof(int)));
+  *out = c;
+  return SPS_OK;
+}
+
+int sps_ctx_destroy(sps_ctx *c) {
+  if (!c) return SPS_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  free_arena(c);
+  (void)hipFree(c->counts);
+  (void)hipFree(c->err);
+  (void)hipFree(c->macc);
+  (void)hipFree(c->pairs);
+  (void)hipFree(c->blob);
+  (void)hipFree(c->ss);
+  if (c->map_keys_alloc) (void)hipFree(c->map_keys_alloc);
+  delete c;
+  return SPS_OK;
+}
+
+int sps_reserve(sps_ctx *c, int64_t max_points) {
+  if (!c || max_points < 0) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (max_points >= (1ll << 30)) return fail(SPS_ERR_INVALID, "max_points too large");
+  return reserve(c, max_points < 1024 ? 1024 : max_points);
+}
+
+int sps_weights_num_tensors(void) { return (int)spec().tensors.size(); }
+
+int sps_weights_tensor_info(int idx, char *name, int name_cap, int64_t *offset, int64_t *numel) {
+  const NetSpec &s = spec();
+  if (idx < 0 || idx >= (int)s.tensors.size()) return fail(SPS_ERR_INVALID, "tensor index %d out of range", idx);
+  const TensorInfo &t = s.tensors[idx];
+  if (name && name_cap > 0) {
+    std::strncpy(name, t.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (offset) *offset = t.off;
+  if (numel) *numel = t.numel;
+  return SPS_OK;
+}
+
+int64_t sps_weights_numel(void) { return spec().numel; }
+
+int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) {
+  const NetSpec &s = spec();
+  if (!c || !blob) return fail(SPS_ERR_INVALID, "null argument");
+  if (numel != s.numel) return fail(SPS_ERR_INVALID, "blob has %lld floats, expected %lld", (long long)numel, (long long)s.numel);
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<float> ss((size_t)s.ss_numel);
+  for (const ConvSpec &cs : s.convs) {
+    float *sc = ss.data() + cs.ss_off, *sh = sc + cs.cout;
+    if (cs.bn.empty()) {
+      for (int j = 0; j < cs.cout; ++j) {
+        sc[j] = 1.f;
+        sh[j] = blob[s.bias_off + j];
+      }
+      continue;
+    }
+    const BnSpec &b = s.bns[s.find_bn(cs.bn)];
+    const float *w = blob + b.off, *bi = w + b.c, *mu = bi + b.c, *var = mu + b.c;
+    for (int j = 0; j < cs.cout; ++j) {
+      // eval BatchNorm1d, eps = 1e-5 (App. A.12): y = (x - mu) / sqrt(var + eps) * w + b
+      const double inv = 1.0 / std::sqrt((double)var[j] + 1e-5);
+      const double scale = (double)w[j] * inv;
+      sc[j] = (float)scale;
+      sh[j] = (float)((double)bi[j] - (double)mu[j] * scale);
+    }
+  }
+  HIP_TRY(hipMemcpy(c->blob, blob, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
+  c->have_weights = true;
+  return SPS_OK;
+}
+
+int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores, void *stream) {
+  if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
+  if (!c->have_weights) return fail(SPS_ERR_NOWEIGHTS, "sps_weights_load has not been called");
+  if (n < 0 || ld < 5 || (n > 0 && (!coords || !scores))) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!(vs > 0.f)) return fail(SPS_ERR_INVALID, "voxel_size must be > 0");
+  if (n >= (1ll << 30)) return fail(SPS_ERR_INVALID, "too many points");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (n > c->cap) {
+    int rc = reserve(c, n);
+    if (rc != SPS_OK) return rc;
+  }
+  c->last_n = n;
+  const int64_t cap = c->cap;
+  // ---- reset hash tables
+  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+    HIP_TRY(hipMemsetAsync(c->lv[l].h.keys, 0xFF, (size_t)c->hcap * sizeof(uint64_t), st));
+    HIP_TRY(hipMemsetAsync(c->lv[l].h.first, 0x7F, (size_t)c->hcap * sizeof(int), st));
+  }
+  HIP_TRY(hipMemsetAsync(c->counts, 0, 5 * sizeof(int), st));
+  if (n == 0) return SPS_OK;
+
+  // ---- level 0: points -> voxels
+  Level &L0 = c->lv[0];
+  hipLaunchKernelGGL(k_points_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coords, ld, (int)n, vs,
+                     L0.h, L0.srckey, L0.pslot, c->err);
+  rank_level(c, L0, nullptr, (int)n, n, c->counts + 0, st);
+  // ---- levels 1..4: stride-2 pyramid
+  for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
+    Level &F = c->lv[l - 1], &L = c->lv[l];
+    const int ts = 1 << (l - 1);
+    hipLaunchKernelGGL(k_parent_insert, dim3(grid_for(cap, 256)), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts,
+                       L.h, L.srckey, L.pslot);
+    rank_level(c, L, c->counts + (l - 1), 0, cap, c->counts + l, st);
+  }
+  // ---- kernel maps
+  const int gx = grid_for(cap, 256, 1024);
+  hipLaunchKernelGGL(k_build_nbr<NBR_5551>, dim3(gx, 125), dim3(256), 0, st, L0.vkeys, c->counts + 0, 1, L0.h,
+                     c->nbr5, cap);
+  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+    Level &L = c->lv[l];
+    hipLaunchKernelGGL(k_build_nbr<NBR_3333>, dim3(gx, 81), dim3(256), 0, st, L.vkeys, c->counts + l, 1 << l, L.h,
+                       L.nbr3, cap);
+  }
+  for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
+    Level &F = c->lv[l - 1], &L = c->lv[l];
+    const int ts = 1 << (l - 1);
+    hipLaunchKernelGGL(k_build_nbr<NBR_DOWN>, dim3(gx, 8), dim3(256), 0, st, L.vkeys, c->counts + l, ts, F.h, L.down,
+                       cap);
+    hipLaunchKernelGGL(k_build_up, dim3(gx), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts, L.inv, L.up, cap);
+  }
+  // ---- network (minkunet.py:161-219)
+  Level *lv = c->lv;
+  const ConvCall calls[] = {
+      {"conv0p1s1", nullptr, 1, c->cat8 + 8, 16, c->nbr5, 0, nullptr, 0, 1},
+      {"conv1p1s2", c->cat8 + 8, 16, c->x1, 8, lv[1].down, 1, nullptr, 0, 1},
+      {"block1.0.conv1", c->x1, 8, c->b1t, 8, lv[1].nbr3, 1, nullptr, 0, 1},
+      {"block1.0.conv2", c->b1t, 8, c->cat7 + 16, 24, lv[1].nbr3, 1, c->x1, 8, 1},
+      {"conv2p2s2", c->cat7 + 16, 24, c->x2, 8, lv[2].down, 2, nullptr, 0, 1},
+      {"block2.0.conv1", c->x2, 8, c->b2t, 16, lv[2].nbr3, 2, nullptr, 0, 1},
+      {"block2.0.downsample.0", c->x2, 8, c->b2r, 16, nullptr, 2, nullptr, 0, 0},
+      {"block2.0.conv2", c->b2t, 16, c->cat6 + 32, 48, lv[2].nbr3, 2, c->b2r, 16, 1},
+      {"conv3p4s2", c->cat6 + 32, 48, c->x3, 16, lv[3].down, 3, nullptr, 0, 1},
+      {"block3.0.conv1", c->x3, 16, c->b3t, 32, lv[3].nbr3, 3, nullptr, 0, 1},
+      {"block3.0.downsample.0", c->x3, 16, c->b3r, 32, nullptr, 3, nullptr, 0, 0},
+      {"block3.0.conv2", c->b3t, 32, c->cat5 + 64, 96, lv[3].nbr3, 3, c->b3r, 32, 1},
+      {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, lv[4].down, 4, nullptr, 0, 1},
+      {"block4.0.conv1", c->x4, 32, c->b4t, 64, lv[4].nbr3, 4, nullptr, 0, 1},
+      {"block4.0.downsample.0", c->x4, 32, c->b4r, 64, nullptr, 4, nullptr, 0, 0},
+      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, lv[4].nbr3, 4, c->b4r, 64, 1},
+      {"convtr4p16s2", c->b4o, 64, c->cat5, 96, lv[4].up, 3, nullptr, 0, 1},
+      {"block5.0.conv1", c->cat5, 96, c->b5t, 64, lv[3].nbr3, 3, nullptr, 0, 1},
+      {"block5.0.downsample.0", c->cat5, 96, c->b5r, 64, nullptr, 3, nullptr, 0, 0},
+      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, lv[3].nbr3, 3, c->b5r, 64, 1},
+      {"convtr5p8s2", c->b5o, 64, c->cat6, 48, lv[3].up, 2, nullptr, 0, 1},
+      {"block6.0.conv1", c->cat6, 48, c->b6t, 32, lv[2].nbr3, 2, nullptr, 0, 1},
+      {"block6.0.downsample.0", c->cat6, 48, c->b6r, 32, nullptr, 2, nullptr, 0, 0},
+      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, lv[2].nbr3, 2, c->b6r, 32, 1},
+      {"convtr6p4s2", c->b6o, 32, c->cat7, 24, lv[2].up, 1, nullptr, 0, 1},
+      {"block7.0.conv1", c->cat7, 24, c->b7t, 16, lv[1].nbr3, 1, nullptr, 0, 1},
+      {"block7.0.downsample.0", c->cat7, 24, c->b7r, 16, nullptr, 1, nullptr, 0, 0},
+      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, lv[1].nbr3, 1, c->b7r, 16, 1},
+      {"convtr7p2s2", c->b7o, 16, c->cat8, 16, lv[1].up, 0, nullptr, 0, 1},
+      {"block8.0.conv1", c->cat8, 16, c->b8t, 8, lv[0].nbr3, 0, nullptr, 0, 1},
+      {"block8.0.downsample.0", c->cat8, 16, c->b8r, 8, nullptr, 0, nullptr, 0, 0},
+      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, lv[0].nbr3, 0, c->b8r, 8, 1},
+      {"final", c->b8o, 8, c->logits, 1, nullptr, 0, nullptr, 0, 0},
+  };
+  for (const ConvCall &cc : calls) {
+    int rc = run_conv(c, cc, st);
+    if (rc != SPS_OK) return rc;
+  }
+  hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->logits, L0.inv, (int)n,
+                     scores);
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_check(sps_ctx *c, void *stream) {
+  if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  int e = 0;
+  HIP_TRY(hipMemcpyAsync(&e, c->err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (e) {
+    HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), st));
+    return fail(SPS_ERR_RANGE,
+                "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");
+  }
+  return SPS_OK;
+}
+
+int sps_metrics(sps_ctx *c, const float *scores, const float *batch, int64_t ld, int64_t n, float eps, int n_batches,
+                double *out_host, void *stream) {
+  if (!c || !out_host) return fail(SPS_ERR_INVALID, "null argument");
+  if (n_batches < 1 || n_batches > 31) return fail(SPS_ERR_INVALID, "n_batches must be in [1,31]");
+  if (n < 0 || ld < 6 || (n > 0 && (!scores || !batch))) return fail(SPS_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(c->macc, 0, (size_t)n_batches * 8 * sizeof(double), st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
+                       n_batches, c->macc);
+  HIP_TRY(hipMemcpyAsync(out_host, c->macc, (size_t)n_batches * 8 * sizeof(double), hipMemcpyDeviceToHost, st));
+  int e = 0;
+  HIP_TRY(hipMemcpyAsync(&e, c->err, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  if (e) {
+    HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), st));
+    return fail(SPS_ERR_RANGE, "a coordinate is outside the voxel-key range");
+  }
+  return SPS_OK;
+}
+
+static int map_upload_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_t m, float ds, void *stream) {
+  if (!c || m < 0 || ld < 3 || (m > 0 && !src)) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!ijk && !(ds > 0.f)) return fail(SPS_ERR_INVALID, "ds must be > 0");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t need = next_pow2(2 * (m < 512 ? 512 : m));
+  if (need > c->map_cap) {
+    HIP_TRY(hipDeviceSynchronize());
+    if (c->map_keys_alloc) (void)hipFree(c->map_keys_alloc);
+    c->map_keys_alloc = nullptr;
+    c->map_cap = 0;
+    hipError_t e = hipMalloc(&c->map_keys_alloc, (size_t)need * sizeof(uint64_t));
+    if (e != hipSuccess) return fail(SPS_ERR_NOMEM, "hipMalloc map hash failed: %s", hipGetErrorString(e));
+    c->map_cap = need;
+  }
+  c->map.keys = (uint64_t *)c->map_keys_alloc;
+  c->map.first = nullptr;
+  c->map.rank = nullptr;
+  c->map.mask = (uint32_t)(c->map_cap - 1);
+  c->map_ds = ds;
+  HIP_TRY(hipMemsetAsync(c->map.keys, 0xFF, (size_t)c->map_cap * sizeof(uint64_t), st));
+  if (m > 0) {
+    const dim3 g((unsigned)((m + 255) / 256));
+    if (ijk)
+      hipLaunchKernelGGL(k_map_insert<true>, g, dim3(256), 0, st, src, ld, m, ds, c->map, c->err);
+    else
+      hipLaunchKernelGGL(k_map_insert<false>, g, dim3(256), 0, st, src, ld, m, ds, c->map, c->err);
+  }
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_t n, float ds, float *out_xyz,
+                       int64_t *n_sub, int64_t *n_scan_vox, void *stream) {
+  if (!c || !n_sub || !n_scan_vox) return fail(SPS_ERR_INVALID, "null argument");
+  if (!c->map.keys) return fail(SPS_ERR_INVALID, "sps_map_upload has not been called");
+  if (n < 0 || ld < 3 || (n > 0 && (!src || !out_xyz))) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!(ds > 0.f)) return fail(SPS_ERR_INVALID, "ds must be > 0");
+  if (n >= (1ll << 30)) return fail(SPS_ERR_INVALID, "too many points");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  *n_sub = 0;
+  *n_scan_vox = 0;
+  if (n == 0) return SPS_OK;
+  if (n > c->cap) {
+    int rc = reserve(c, n);
+    if (rc != SPS_OK) return rc;
+  }
+  Level &L = c->lv[0];  // borrow the level-0 scratch (a forward re-initialises it)
+  HIP_TRY(hipMemsetAsync(L.h.keys, 0xFF, (size_t)c->hcap * sizeof(uint64_t), st));
+  HIP_TRY(hipMemsetAsync(L.h.first, 0x7F, (size_t)c->hcap * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(c->counts + 5, 0, 2 * sizeof(int), st));
+  const unsigned g = (unsigned)((n + 255) / 256);
+  if (ijk)
+    hipLaunchKernelGGL(k_scan_trunc_insert<true>, dim3(g), dim3(256), 0, st, src, ld, (int)n, ds, L.h, L.srckey,
+                       L.pslot, c->err);
+  else
+    hipLaunchKernelGGL(k_scan_trunc_insert<false>, dim3(g), dim3(256), 0, st, src, ld, (int)n, ds, L.h, L.srckey,
+                       L.pslot, c->err);
+  hipLaunchKernelGGL(k_submap_filter, dim3(g), dim3(256), 0, st, L.pslot, L.h.first, L.srckey, (int)n, c->map,
+                     c->keep, c->counts + 6);
+  const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  hipLaunchKernelGGL(k_keep_count, dim3(nb), dim3(SCAN_BLOCK), 0, st, c->keep, (int)n, c->block_sums);
+  hipLaunchKernelGGL(k_keep_write, dim3(nb), dim3(SCAN_BLOCK), 0, st, c->keep, L.srckey, (int)n, ds, c->block_sums,
+                     out_xyz, c->counts + 5);
+  int res[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(res, c->counts + 5, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *n_sub = res[0];
+  *n_scan_vox = res[1];
+  c->last_n = 0;
+  return SPS_OK;
+}
+
+int sps_map_upload(sps_ctx *c, const float *xyz, int64_t ld, int64_t m, float ds, void *stream) {
+  return map_upload_impl(c, xyz, false, ld, m, ds, stream);
+}
+int sps_map_upload_voxels(sps_ctx *c, const int32_t *ijk, int64_t ld, int64_t m, void *stream) {
+  return map_upload_impl(c, ijk, true, ld, m, 0.f, stream);
+}
+int sps_submap_voxel(sps_ctx *c, const float *scan_xyz, int64_t ld, int64_t n, float *out_xyz, int64_t *n_sub,
+                     int64_t *n_scan_vox, void *stream) {
+  if (c && !(c->map_ds > 0.f)) return fail(SPS_ERR_INVALID, "the map was uploaded as voxels: use sps_submap_voxel_ijk");
+  return submap_impl(c, scan_xyz, false, ld, n, c ? c->map_ds : 0.f, out_xyz, n_sub, n_scan_vox, stream);
+}
+int sps_submap_voxel_ijk(sps_ctx *c, const int32_t *scan_ijk, int64_t ld, int64_t n, float ds, float *out_xyz,
+                         int64_t *n_sub, int64_t *n_scan_vox, void *stream) {
+  return submap_impl(c, scan_ijk, true, ld, n, ds, out_xyz, n_sub, n_scan_vox, stream);
+}
+
+// ---- introspection ---------------------------------------------------------------------------
+int sps_level_counts(sps_ctx *c, int64_t out[SPS_NUM_LEVELS]) {
+  if (!c || !out) return fail(SPS_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());
+  int h[SPS_NUM_LEVELS];
+  HIP_TRY(hipMemcpy(h, c->counts, sizeof h, hipMemcpyDeviceToHost));
+  for (int l = 0; l < SPS_NUM_LEVELS; ++l) out[l] = h[l];
+  return SPS_OK;
+}
+
+int sps_get_voxels(sps_ctx *c, int level, int32_t *coords_dev) {
+  if (!c || !coords_dev || level < 0 || level >= SPS_NUM_LEVELS) return fail(SPS_ERR_INVALID, "bad arguments");
+  int64_t cnt[SPS_NUM_LEVELS];
+  int rc = sps_level_counts(c, cnt);
+  if (rc != SPS_OK) return rc;
+  const int n = (int)cnt[level];
+  if (n > 0)
+    hipLaunchKernelGGL(k_keys_to_coords, dim3((n + 255) / 256), dim3(256), 0, 0, c->lv[level].vkeys, n, coords_dev);
+  HIP_TRY(hipDeviceSynchronize());
+  return SPS_OK;
+}
+
+int sps_get_inverse(sps_ctx *c, int64_t *inv_dev) {
+  if (!c || !inv_dev) return fail(SPS_ERR_INVALID, "null argument");
+  HIP_TRY(hipSetDevice(c->device));
+  const int n = (int)c->last_n;
+  if (n > 0) hipLaunchKernelGGL(k_i32_to_i64, dim3((n + 255) / 256), dim3(256), 0, 0, c->lv[0].inv, n, inv_dev);
+  HIP_TRY(hipDeviceSynchronize());
+  return SPS_OK;
+}
+
+int sps_get_parent(sps_ctx *c, int level, int32_t *parent_dev) {
+  if (!c || !parent_dev || level < 0 || level >= SPS_NUM_LEVELS - 1) return fail(SPS_ERR_INVALID, "bad arguments");
+  int64_t cnt[SPS_NUM_LEVELS];
+  int rc = sps_level_counts(c, cnt);
+  if (rc != SPS_OK) return rc;
+  HIP_TRY(hipMemcpy(parent_dev, c->lv[level + 1].inv, (size_t)cnt[level] * sizeof(int), hipMemcpyDeviceToDevice));
+  return SPS_OK;
+}
+
+int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
+  if (!c || !pairs_host || which < 0 || which > 5) return fail(SPS_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  const int K = which == 5 ? 125 : 81;
+  const int level = which == 5 ? 0 : which;
+  const int *nbr = which == 5 ? c->nbr5 : c->lv[which].nbr3;
+  HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
+  hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, c->cap,
+                     c->counts + level, c->pairs);
+  unsigned long long h[128];
+  HIP_TRY(hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost));
+  for (int k = 0; k < K; ++k) pairs_host[k] = (int64_t)h[k];
+  return SPS_OK;
+}
+
+int sps_get_logits(sps_ctx *c, float *logits_dev) {
+  if (!c || !logits_dev) return fail(SPS_ERR_INVALID, "null argument");
+  int64_t cnt[SPS_NUM_LEVELS];
+  int rc = sps_level_counts(c, cnt);
+  if (rc != SPS_OK) return rc;
+  HIP_TRY(hipMemcpy(logits_dev, c->logits, (size_t)cnt[0] * sizeof(float), hipMemcpyDeviceToDevice));
+  return SPS_OK;
+}
+
+int sps_get_feature(sps_ctx *c, const char *name, float *out_dev, int64_t *rows, int64_t *cols) {
+  if (!c || !name || !rows || !cols) return fail(SPS_ERR_INVALID, "null argument");
+  int64_t cnt[SPS_NUM_LEVELS];
+  int rc = sps_level_counts(c, cnt);
+  if (rc != SPS_OK) return rc;
+  for (const Feat &f : feature_taps(c)) {
+    if (std::strcmp(f.name, name) != 0) continue;
+    *rows = cnt[f.level];
+    *cols = f.cols;
+    if (out_dev && *rows > 0) {
+      const int64_t tot = *rows * f.cols;
+      hipLaunchKernelGGL(k_copy_strided, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, f.ptr, f.ld, (int)*rows,
+                         f.cols, out_dev);
+      HIP_TRY(hipDeviceSynchronize());
+    }
+    return SPS_OK;
+  }
+  return fail(SPS_ERR_INVALID, "unknown feature tap '%s'", name);
+}
+
+}  // extern "C"

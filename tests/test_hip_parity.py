@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP path (through the C ABI / the sps.* drop-in API) against the oracle
+on the same seeded inputs.  Integer work (voxels, inverse map, parents, kernel-map pair counts,
+labels, confusion counts) must be exact; logits within 1e-3 (north_star), asserted tighter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sps_oracle as O
+from sps_amd import synthetic
+from tests.helpers import CFG, net_from_params
+
+pytestmark = pytest.mark.gpu
+
+VS = CFG["MODEL"]["VOXEL_SIZE"]
+EPS = CFG["FILTER"]["THRESHOLD"]
+
+
+@pytest.fixture(scope="module")
+def params():
+    return O.random_params(seed=0)
+
+
+@pytest.fixture(scope="module")
+def net(params):
+    assert torch.cuda.is_available()
+    return net_from_params(params).cuda().eval().freeze()
+
+
+def ctx():
+    from sps_amd.models.models import get_context
+    return get_context(0)
+
+
+def run(net, batch_np):
+    dev = torch.from_numpy(np.ascontiguousarray(batch_np)).cuda()
+    scores = net(dev)
+    torch.cuda.synchronize()
+    return dev, scores
+
+
+def get_voxels(level, count):
+    out = torch.empty((count, 5), dtype=torch.int32, device="cuda")
+    from sps_amd import _native
+    _native.check(_native.lib.sps_get_voxels(ctx().handle, level, out.data_ptr()))
+    return out.cpu().numpy()
+
+
+def get_feature(name):
+    import ctypes as C
+    from sps_amd import _native
+    r, c = C.c_int64(), C.c_int64()
+    _native.check(_native.lib.sps_get_feature(ctx().handle, name.encode(), None, C.byref(r), C.byref(c)))
+    out = torch.empty((r.value, c.value), dtype=torch.float32, device="cuda")
+    _native.check(_native.lib.sps_get_feature(ctx().handle, name.encode(), out.data_ptr(), C.byref(r), C.byref(c)))
+    return out.cpu().numpy()
+
+
+def check_full(net, params, batch, tol=2e-4):
+    dev, scores = run(net, batch)
+    ref, info = O.sps_forward(params, batch[:, :5], VS, keep=True)
+    counts = ctx().level_counts()
+    cm = info["cm"]
+    # --- integer structure: exact, including row order (both sides use first-occurrence order)
+    for l in range(5):
+        ts = 1 << l
+        assert counts[l] == len(cm.coords[ts]), f"level {l}"
+        np.testing.assert_array_equal(get_voxels(l, counts[l]), cm.coords[ts])
+    from sps_amd import _native
+    inv = torch.empty(len(batch), dtype=torch.int64, device="cuda")
+    _native.check(_native.lib.sps_get_inverse(ctx().handle, inv.data_ptr()))
+    np.testing.assert_array_equal(inv.cpu().numpy(), info["inverse"])
+    for l in range(4):
+        par = torch.empty(counts[l], dtype=torch.int32, device="cuda")
+        _native.check(_native.lib.sps_get_parent(ctx().handle, l, par.data_ptr()))
+        np.testing.assert_array_equal(par.cpu().numpy(), cm.parent[1 << l])
+    for l in range(5):
+        want = [len(i) for i, _ in cm.k3(1 << l)]
+        assert ctx().map_pairs(l) == want, f"3^4 map level {l}"
+    assert ctx().map_pairs(5) == [len(i) for i, _ in cm.k5()]
+    # --- features
+    for name, want in info["inter"].items():
+        got = get_feature(name)
+        np.testing.assert_allclose(got, want, rtol=tol, atol=tol, err_msg=name)
+    logits = torch.empty(counts[0], dtype=torch.float32, device="cuda")
+    _native.check(_native.lib.sps_get_logits(ctx().handle, logits.data_ptr()))
+    np.testing.assert_allclose(logits.cpu().numpy(), info["logits"], rtol=0, atol=1e-3)
+    s = scores.cpu().numpy()
+    np.testing.assert_allclose(s, ref, rtol=0, atol=1e-4)
+    # --- labels: identical outside a tiny band around the threshold
+    e = np.float32(EPS)
+    band = np.abs(ref - e) > 1e-5
+    np.testing.assert_array_equal((s < e)[band], (ref < e)[band])
+    return dev, s, ref
+
+
+def test_small_scene_full_parity(net, params):
+    check_full(net, params, synthetic.small_scene(seed=0, n_scan=2000))
+
+
+def test_other_seed_and_default_bn(params):
+    p = O.random_params(seed=7, randomize_bn=False)
+    n = net_from_params(p).cuda().eval().freeze()
+    check_full(n, p, synthetic.small_scene(seed=5, n_scan=1500))
+
+
+def test_negative_octants_and_requantised_corners(net, params):
+    """Submap rows are voxel corners ix*0.1f that re-quantise to ix-1 for some negatives (App. E)."""
+    b = synthetic.small_scene(seed=2, n_scan=1200, extent=4.0)
+    b[:, 1:4] -= 7.3
+    check_full(net, params, b)
+
+
+def test_metrics_match_oracle(net, params):
+    batch = synthetic.small_scene(seed=11, n_scan=2500)
+    dev, s, ref = check_full(net, params, batch)
+    m = net.predict_step(dev, 0)
+    mo = O.predict_metrics(s, batch, EPS)          # same scores -> counts must be exact
+    for k in ("precision", "recall", "f1", "accuracy", "dIoU"):
+        assert m[k] == pytest.approx(mo[k], abs=1e-12), k
+    assert m["loss"] == pytest.approx(mo["loss"], rel=1e-9)
+    assert m["r2"] == pytest.approx(mo["r2"], rel=1e-8)
+    assert net.dIoU[-1] == m["dIoU"] and len(net.predict_loss) >= 1
+
+
+def test_batch_independence(net, params):
+    """b = 0..2 batched == three single runs (b is never convolved across, App. A.5)."""
+    parts = [synthetic.small_scene(seed=20 + i, n_scan=900) for i in range(3)]
+    singles = []
+    for p in parts:
+        _, s = run(net, p)
+        singles.append(s.cpu().numpy())
+    stacked = []
+    for i, p in enumerate(parts):
+        q = p.copy()
+        q[:, 0] = i
+        stacked.append(q)
+    big = np.concatenate(stacked, 0)
+    dev, s = run(net, big)
+    np.testing.assert_array_equal(s.cpu().numpy(), np.concatenate(singles))   # bit-exact: same sums
+    per = net.step_metrics(dev, s, n_batches=3)
+    for i, p in enumerate(parts):
+        mo = O.predict_metrics(singles[i], p, EPS)
+        from sps_amd.models.models import metrics_from_sums
+        assert metrics_from_sums(per[i])["dIoU"] == pytest.approx(mo["dIoU"], abs=1e-12, nan_ok=True)
+
+
+def test_permutation_and_duplicates(net, params):
+    batch = synthetic.small_scene(seed=4, n_scan=1000)
+    _, s0 = run(net, batch)
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(len(batch))
+    _, s1 = run(net, batch[perm])
+    np.testing.assert_array_equal(s1.cpu().numpy(), s0.cpu().numpy()[perm])   # order-free, bit-exact
+    dup = np.concatenate([batch, batch[:300]], 0)
+    _, s2 = run(net, dup)
+    np.testing.assert_array_equal(s2.cpu().numpy()[: len(batch)], s0.cpu().numpy())
+    np.testing.assert_array_equal(s2.cpu().numpy()[len(batch):], s0.cpu().numpy()[:300])
+
+
+def test_edge_cases(net, params):
+    # empty
+    e = torch.empty((0, 6), dtype=torch.float32, device="cuda")
+    assert net(e).shape == (0,)
+    # single point: conv chain on one voxel
+    one = np.array([[0, 1.23, -4.56, 0.78, 1, 0.3]], np.float32)
+    check_full(net, params, one)
+    # two points in one voxel get the same score
+    two = np.array([[0, 1.21, -4.56, 0.78, 1, 0.3], [0, 1.29, -4.51, 0.71, 1, 0.9]], np.float32)
+    _, s = run(net, two)
+    assert s[0].item() == s[1].item()
+
+
+def test_out_of_range_is_reported(net):
+    from sps_amd._native import SpsError
+    bad = np.array([[0, 2.0e4, 0, 0, 1, 0.5], [0, 1.0, 1.0, 1.0, 1, 0.5]], np.float32)   # 200 000 voxels away
+    dev = torch.from_numpy(bad).cuda()
+    s = net(dev)
+    with pytest.raises(SpsError) as ei:
+        ctx().check_errors(torch.cuda.current_stream().cuda_stream)
+    assert ei.value.code == -4
+    s = s.cpu().numpy()
+    assert np.isnan(s[0]) and np.isfinite(s[1])
+    ctx().check_errors(torch.cuda.current_stream().cuda_stream)          # flag was cleared
+
+
+def test_quantisation_probe_matches_f32_division():
+    """SURVEY App. C probe: floor(x / f32(0.1)) must be IEEE f32 division (not x*10, not f64)."""
+    rng = np.random.default_rng(123)
+    n = 1_000_000
+    pts = np.zeros((n, 5), np.float32)
+    pts[:, 1:4] = rng.uniform(-100, 100, (n, 3)).astype(np.float32)
+    pts[:, 4] = 1
+    p = O.random_params(seed=1)
+    net = net_from_params(p).cuda().eval().freeze()
+    dev = torch.from_numpy(pts).cuda()
+    net(dev)
+    counts = ctx().level_counts()
+    vox = get_voxels(0, counts[0])
+    want, inv = O.unique_first(O.quantize(pts, VS))
+    np.testing.assert_array_equal(vox, want)
+
+
+def test_prune_matches_oracle():
+    import sps.datasets.util as util
+    rng = np.random.default_rng(5)
+    map_xyz = rng.uniform(-8, 8, (20000, 3)).astype(np.float32)
+    scan_xyz = (map_xyz[:6000] + rng.normal(0, 0.05, (6000, 3))).astype(np.float32)
+    scan_xyz = np.concatenate([scan_xyz, scan_xyz[:500]], 0)                     # duplicates
+    mcf = util.to_coords_features(torch.from_numpy(map_xyz).cuda(), "map", VS)
+    scf = util.to_coords_features(torch.from_numpy(scan_xyz).cuda(), "scan", VS)
+    np.testing.assert_array_equal(scf.cloud_coords.cpu().numpy(), O.to_coords(scan_xyz, VS))
+    sub, n_scan_vox = util.prune(mcf, scf, VS)
+    want, n_want = O.prune(O.to_coords(map_xyz, VS), O.to_coords(scan_xyz, VS), VS)
+    assert n_scan_vox == n_want
+    np.testing.assert_array_equal(sub.cpu().numpy(), want)       # same order: scan first-occurrence
+    # float entry point (fused truncation) gives the same rows
+    from sps_amd.models.models import get_context
+    c = get_context(0)
+    st = torch.cuda.current_stream().cuda_stream
+    m = torch.from_numpy(map_xyz).cuda(); sc = torch.from_numpy(scan_xyz).cuda()
+    c.map_upload(m.data_ptr(), 3, len(m), VS, st)
+    out = torch.empty((len(sc), 3), dtype=torch.float32, device="cuda")
+    a, b = c.submap_voxel(sc.data_ptr(), 3, len(sc), out.data_ptr(), st)
+    assert (a, b) == (len(want), n_want)
+    np.testing.assert_array_equal(out[:a].cpu().numpy(), want)
+    util._MAP_CACHE.clear()
+
+
+def test_infer_helper(net, params):
+    import sps.datasets.util as util
+    batch = synthetic.small_scene(seed=9, n_scan=800)
+    ns = int((batch[:, 4] == 1).sum())
+    scan = torch.from_numpy(batch[:ns, 1:4]).cuda()
+    sub = torch.from_numpy(batch[ns:, 1:4]).cuda()
+    scores, dt = util.infer(scan, sub, net)
+    ref, _ = O.sps_forward(params, batch[:, :5], VS)
+    np.testing.assert_allclose(scores.cpu().numpy(), ref[:ns], atol=1e-4)
+    with pytest.raises(AssertionError, match="Expected 3 columns"):
+        util.infer(torch.zeros(4, 4).cuda(), sub, net)
+
+
+@pytest.mark.timeout(600)
+def test_config2_full_size_parity(net, params):
+    """BASELINE config 2 (~100k-pt scan + submap, 0.1 m): full oracle comparison."""
+    sc = synthetic.make_scene(scan_seed=1)
+    check_full(net, params, sc["batch"], tol=5e-4)
