@@ -97,6 +97,12 @@ int sps_check(sps_ctx *ctx, void *stream);
 int sps_metrics(sps_ctx *ctx, const float *scores_dev, const float *batch_dev, int64_t ld, int64_t n,
                 float eps, int n_batches, double *out_host, void *stream);
 
+/* Same accumulators written to DEVICE memory out_dev[n_batches*8] (doubles) without synchronising:
+ * lets a streaming loop keep per-scan metric rows on the device and gather them once per sequence
+ * (RCCL all-gather in the multi-GPU predict loop). */
+int sps_metrics_dev(sps_ctx *ctx, const float *scores_dev, const float *batch_dev, int64_t ld, int64_t n,
+                    float eps, int n_batches, double *out_dev, void *stream);
+
 /* ---- variant-B submap (online path) ---------------------------------------------------
  * Replaces util.to_coords_features + util.prune (reference util.py:67-114): voxel =
  * trunc(xyz / ds) in f32; the map's unique voxel set is kept in a device-resident hash
@@ -113,6 +119,16 @@ int sps_submap_voxel(sps_ctx *ctx, const float *scan_xyz_dev, int64_t ld, int64_
                      int64_t *n_sub, int64_t *n_scan_vox, void *stream);
 int sps_submap_voxel_ijk(sps_ctx *ctx, const int32_t *scan_ijk_dev, int64_t ld, int64_t n, float ds,
                          float *out_xyz_dev, int64_t *n_sub, int64_t *n_scan_vox, void *stream);
+
+/* ---- per-stage timing (hipEvents on the caller's stream; for bench.py / DESIGN.md) ------
+ * With profiling on, sps_forward records one event after every stage ("reset", "voxelize",
+ * "pyramid", "maps", one per convolution by state_dict name, "slice_sigmoid").  After a forward,
+ * sps_profile_count gives the number of stages and sps_profile_read(i) synchronises on stage i's
+ * closing event and returns its name and duration in milliseconds.  Replaces the reference's
+ * time.time() deltas (util.py:164,182; sps_node.py:164-176). */
+int sps_profile_enable(sps_ctx *ctx, int on);
+int sps_profile_count(sps_ctx *ctx);
+int sps_profile_read(sps_ctx *ctx, int idx, char *name, int name_cap, float *ms);
 
 /* ---- introspection (parity tests; all synchronise) ----------------------------------- */
 /* Number of active voxels at each tensor stride of the last forward. */

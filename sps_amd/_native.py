@@ -40,6 +40,10 @@ def _load() -> C.CDLL:
         "sps_forward": (i32, [vp, vp, i64, i64, f32, vp, vp]),
         "sps_check": (i32, [vp, vp]),
         "sps_metrics": (i32, [vp, vp, vp, i64, i64, f32, i32, C.POINTER(C.c_double), vp]),
+        "sps_metrics_dev": (i32, [vp, vp, vp, i64, i64, f32, i32, vp, vp]),
+        "sps_profile_enable": (i32, [vp, i32]),
+        "sps_profile_count": (i32, [vp]),
+        "sps_profile_read": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(f32)]),
         "sps_map_upload": (i32, [vp, vp, i64, i64, f32, vp]),
         "sps_map_upload_voxels": (i32, [vp, vp, i64, i64, vp]),
         "sps_submap_voxel": (i32, [vp, vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp]),
@@ -62,7 +66,8 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
-           "sps_forward", "sps_check", "sps_metrics", "sps_map_upload", "sps_map_upload_voxels",
+           "sps_forward", "sps_check", "sps_metrics", "sps_metrics_dev",
+           "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_level_counts", "sps_get_voxels",
            "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_logits", "sps_get_feature"]
 
@@ -120,6 +125,23 @@ class Context:
         out = (C.c_double * (8 * n_batches))()
         check(lib.sps_metrics(self.handle, scores_ptr, batch_ptr, ld, n, eps, n_batches, out, stream))
         return [list(out[8 * b: 8 * b + 8]) for b in range(n_batches)]
+
+    def metrics_dev(self, scores_ptr: int, batch_ptr: int, ld: int, n: int, eps: float, n_batches: int,
+                    out_ptr: int, stream: int):
+        check(lib.sps_metrics_dev(self.handle, scores_ptr, batch_ptr, ld, n, eps, n_batches, out_ptr, stream))
+
+    def profile_enable(self, on: bool):
+        check(lib.sps_profile_enable(self.handle, 1 if on else 0))
+
+    def profile_read(self):
+        """[(stage name, milliseconds)] of the last forward (synchronises on the stage events)."""
+        out = []
+        buf = C.create_string_buffer(96)
+        ms = C.c_float()
+        for i in range(lib.sps_profile_count(self.handle)):
+            check(lib.sps_profile_read(self.handle, i, buf, 96, C.byref(ms)))
+            out.append((buf.value.decode(), ms.value))
+        return out
 
     def map_upload(self, xyz_ptr: int, ld: int, m: int, ds: float, stream: int):
         check(lib.sps_map_upload(self.handle, xyz_ptr, ld, m, ds, stream))

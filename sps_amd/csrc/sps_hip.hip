@@ -794,6 +794,11 @@ struct sps_ctx {
   float *x2 = nullptr, *b2t = nullptr, *b2r = nullptr, *cat6 = nullptr, *b6t = nullptr, *b6r = nullptr, *b6o = nullptr;
   float *x3 = nullptr, *b3t = nullptr, *b3r = nullptr, *cat5 = nullptr, *b5t = nullptr, *b5r = nullptr, *b5o = nullptr;
   float *x4 = nullptr, *b4t = nullptr, *b4r = nullptr, *b4o = nullptr;
+  // per-stage hipEvent profiling (sps_profile_*): off by default
+  bool prof = false;
+  std::vector<hipEvent_t> prof_ev;
+  std::vector<std::string> prof_names;
+  size_t prof_n = 0;
   // map hash (variant-B submap)
   HashTable map{};
   int64_t map_cap = 0;
@@ -963,6 +968,20 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   return SPS_OK;
 }
 
+// records an event that closes the stage `name` (profiling mode only)
+void prof_mark(sps_ctx *c, const char *name, hipStream_t st) {
+  if (!c->prof) return;
+  if (c->prof_n >= c->prof_ev.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    c->prof_ev.push_back(e);
+    c->prof_names.emplace_back();
+  }
+  c->prof_names[c->prof_n] = name;
+  (void)hipEventRecord(c->prof_ev[c->prof_n], st);
+  ++c->prof_n;
+}
+
 std::vector<Feat> feature_taps(sps_ctx *c) {
   return {
       {"out_p1", c->cat8 + 8, 16, 8, 0},  {"block1", c->cat7 + 16, 24, 8, 1}, {"block2", c->cat6 + 32, 48, 16, 2},
@@ -1086,6 +1105,8 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   }
   c->last_n = n;
   const int64_t cap = c->cap;
+  c->prof_n = 0;
+  prof_mark(c, "begin", st);
   // ---- reset hash tables
   for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
     HIP_TRY(hipMemsetAsync(c->lv[l].h.keys, 0xFF, (size_t)c->hcap * sizeof(uint64_t), st));
@@ -1093,12 +1114,14 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   }
   HIP_TRY(hipMemsetAsync(c->counts, 0, 5 * sizeof(int), st));
   if (n == 0) return SPS_OK;
+  prof_mark(c, "reset", st);
 
   // ---- level 0: points -> voxels
   Level &L0 = c->lv[0];
   hipLaunchKernelGGL(k_points_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coords, ld, (int)n, vs,
                      L0.h, L0.srckey, L0.pslot, c->err);
   rank_level(c, L0, nullptr, (int)n, n, c->counts + 0, st);
+  prof_mark(c, "voxelize", st);
   // ---- levels 1..4: stride-2 pyramid
   for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
     Level &F = c->lv[l - 1], &L = c->lv[l];
@@ -1107,6 +1130,7 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
                        L.h, L.srckey, L.pslot);
     rank_level(c, L, c->counts + (l - 1), 0, cap, c->counts + l, st);
   }
+  prof_mark(c, "pyramid", st);
   // ---- kernel maps
   const int gx = grid_for(cap, 256, 1024);
   hipLaunchKernelGGL(k_build_nbr<NBR_5551>, dim3(gx, 125), dim3(256), 0, st, L0.vkeys, c->counts + 0, 1, L0.h,
@@ -1123,6 +1147,7 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
                        cap);
     hipLaunchKernelGGL(k_build_up, dim3(gx), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts, L.inv, L.up, cap);
   }
+  prof_mark(c, "maps", st);
   // ---- network (minkunet.py:161-219)
   Level *lv = c->lv;
   const ConvCall calls[] = {
@@ -1163,10 +1188,33 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   for (const ConvCall &cc : calls) {
     int rc = run_conv(c, cc, st);
     if (rc != SPS_OK) return rc;
+    prof_mark(c, cc.name, st);
   }
   hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->logits, L0.inv, (int)n,
                      scores);
+  prof_mark(c, "slice_sigmoid", st);
   HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_profile_enable(sps_ctx *c, int on) {
+  if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
+  c->prof = on != 0;
+  c->prof_n = 0;
+  return SPS_OK;
+}
+
+int sps_profile_count(sps_ctx *c) { return c && c->prof_n > 0 ? (int)c->prof_n - 1 : 0; }
+
+int sps_profile_read(sps_ctx *c, int idx, char *name, int name_cap, float *ms) {
+  if (!c || !ms || idx < 0 || idx + 1 >= (int)c->prof_n) return fail(SPS_ERR_INVALID, "bad stage index");
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipEventSynchronize(c->prof_ev[idx + 1]));
+  HIP_TRY(hipEventElapsedTime(ms, c->prof_ev[idx], c->prof_ev[idx + 1]));
+  if (name && name_cap > 0) {
+    std::strncpy(name, c->prof_names[idx + 1].c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
   return SPS_OK;
 }
 
@@ -1278,6 +1326,21 @@ static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_
   *n_sub = res[0];
   *n_scan_vox = res[1];
   c->last_n = 0;
+  return SPS_OK;
+}
+
+int sps_metrics_dev(sps_ctx *c, const float *scores, const float *batch, int64_t ld, int64_t n, float eps, int n_batches,
+                    double *out_dev, void *stream) {
+  if (!c || !out_dev) return fail(SPS_ERR_INVALID, "null argument");
+  if (n_batches < 1 || n_batches > 31) return fail(SPS_ERR_INVALID, "n_batches must be in [1,31]");
+  if (n < 0 || ld < 6 || (n > 0 && (!scores || !batch))) return fail(SPS_ERR_INVALID, "bad arguments");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n_batches * 8 * sizeof(double), st));
+  if (n > 0)
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
+                       n_batches, out_dev);
+  HIP_TRY(hipGetLastError());
   return SPS_OK;
 }
 
