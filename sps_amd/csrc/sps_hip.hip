@@ -258,7 +258,7 @@ enum NbrKind { NBR_3333 = 0, NBR_5551 = 1, NBR_DOWN = 2 };
 //   NBR_DOWN : k = dx + 2dy + 4dz, d in {0,1} * ts (ts = stride of the INPUT = finer level)
 template <int KIND>
 __global__ void k_build_nbr(const uint64_t *__restrict__ out_keys, const int *__restrict__ n_out, int ts,
-                            HashTable in, int *__restrict__ nbr, int64_t ldn) {
+                            HashTable in, int *__restrict__ nbr, int64_t ldn, uint32_t *__restrict__ tmask) {
   const int n = *n_out;
   const int k = blockIdx.y;
   int dx, dy, dz, dt = 0;
@@ -276,6 +276,8 @@ __global__ void k_build_nbr(const uint64_t *__restrict__ out_keys, const int *__
     dy = ((k >> 1) & 1) * ts;
     dz = ((k >> 2) & 1) * ts;
   }
+  // blockDim.x and the grid stride are multiples of 64, so lane l always handles a row = l (mod 64):
+  // a 16-lane segment of the wave is one 16-row tile of the output-stationary convolution.
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
     int b, x, y, z, t;
     key_unpack(out_keys[u], b, x, y, z, t);
@@ -286,13 +288,18 @@ __global__ void k_build_nbr(const uint64_t *__restrict__ out_keys, const int *__
     int r = -1;
     if (key_in_range(b, x, y, z, t)) r = hash_lookup(in, key_pack(b, x, y, z, t));
     nbr[(size_t)k * ldn + u] = r;
+    // tile mask: bit k of tile (u >> 4) = "some row of the tile has a neighbour through offset k"
+    const unsigned long long bal = __ballot(r >= 0);
+    const int lane = threadIdx.x & 63;
+    if ((lane & 15) == 0 && ((bal >> lane) & 0xFFFFull)) atomicOr(&tmask[(size_t)(u >> 4) * 4 + (k >> 5)], 1u << (k & 31));
   }
 }
 
 // transposed conv map (App. A.10): fine voxel v receives exactly one term, from its parent, through
 // offset k = octant of v inside the parent:  up[k*ldn + v] = (k == oct(v)) ? parent[v] : -1.
 __global__ void k_build_up(const uint64_t *__restrict__ fine_keys, const int *__restrict__ n_fine, int ts,
-                           const int *__restrict__ parent, int *__restrict__ up, int64_t ldn) {
+                           const int *__restrict__ parent, int *__restrict__ up, int64_t ldn,
+                           uint32_t *__restrict__ tmask) {
   const int n = *n_fine;
   int sh = 0;
   while ((1 << sh) < ts) ++sh;
@@ -300,8 +307,13 @@ __global__ void k_build_up(const uint64_t *__restrict__ fine_keys, const int *__
     const uint64_t key = fine_keys[v];
     const int oct = (int)((key >> sh) & 1) | ((int)((key >> (18 + sh)) & 1) << 1) | ((int)((key >> (36 + sh)) & 1) << 2);
     const int par = parent[v];
+    const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) up[(size_t)k * ldn + v] = (k == oct) ? par : -1;
+    for (int k = 0; k < 8; ++k) {
+      up[(size_t)k * ldn + v] = (k == oct) ? par : -1;
+      const unsigned long long bal = __ballot(k == oct && par >= 0);
+      if ((lane & 15) == 0 && ((bal >> lane) & 0xFFFFull)) atomicOr(&tmask[(size_t)(v >> 4) * 4], 1u << k);
+    }
   }
 }
 
@@ -322,74 +334,125 @@ __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, const in
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 
 struct ConvArgs {
-  const float *in;     // [*, ldi]
-  float *out;          // [*, ldo]
-  const float *W;      // [K*cin, cout] (= [K][cin][cout] flattened)
-  const float *scale;  // [cout]  folded BN (or 1)
-  const float *shift;  // [cout]  folded BN (or bias)
-  const float *res;    // residual [*, ldr] or null
-  const int *nbr;      // [K][ldn] or null (identity, K == 1)
-  const int *n_out;    // device count of output rows
-  int64_t ldn;
+  const float *in;        // [*, ldi]
+  float *out;             // [*, ldo]
+  const float *Wu;        // unit-major permuted weights (see permute_weights)
+  const float *scale;     // [cout]  folded BN (or 1)
+  const float *shift;     // [cout]  folded BN (or bias)
+  const float *res;       // residual [*, ldr] or null
+  const int *nbr;         // [K][ldn] or null (identity, K == 1)
+  const uint32_t *tmask;  // [tiles][4] present-offset mask per 16-row tile, or null (K == 1)
+  const int *n_out;       // device count of output rows
+  float *slab;            // split-K partial sums [S][slab_stride] (S > 1)
+  int64_t ldn, slab_stride;
   int ldi, ldo, ldr;
-  int K, cin, cout;
-  int relu;
+  int K, cin, cout, NT, upk;
+  int relu, S;
+  float inv_upk;
   float in_const;  // cin == 1: constant input feature (0.5, models.py:22) when in == null
 };
 
-// One wave = 16 output rows x (NT*16) output channels.  The GEMM K dimension is the flattened
-// (offset k, input channel) index j = k*cin + ci, i.e. W viewed as [K*cin][cout]; A[row][j] is the
-// gathered input feature (0 when the neighbour is absent).  v_mfma_f32_16x16x4_f32 lane map
-// (cdna_hip_programming.md section 3): lane l holds A[l&15][l>>4] and B[l>>4][l&15]; each lane
-// loads one float4 (4 consecutive ci of "unit" u = 4g + (l>>4)) and feeds it over 4 MFMA steps, so
-// that step s multiplies A[.][j = 4u+s] by B[j = 4u+s][.] -- a permutation of the K order inside a
-// group of 16, which a sum does not see.  Groups whose 16 rows have no present neighbour are skipped.
-template <int NT>
-__global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
+// Output-stationary sparse convolution on f32 MFMA.
+//   One wave = one 16-row output tile x (NTW*16) output channels x one split of the tile's work list.
+//   Work list of a tile = the offsets k present for at least one of its rows (tile mask -> compact
+//   list, built in the prologue), expanded to "units" (k, c4) of 4 consecutive input channels.
+//   v_mfma_f32_16x16x4_f32 lane map (cdna_hip_programming.md section 3): lane l holds A[l&15][l>>4] and
+//   B[l>>4][l&15].  Lane group q = l>>4 walks units j = 4i+q of the list: it gathers ONE float4 of its
+//   row (A) and ONE float4 of unit-major weights (B) and feeds them over 4 MFMA steps; the MFMA's
+//   K-sum adds the 4 lane groups, so the K order inside a step is a permutation of (k, ci) -- which a
+//   sum does not see; across steps offsets ascend as in ME (App. A.8).
+//   Weights: Wu[u][nt][n][s] = W[k][4*c4+s][16*nt+n], u = k*upk + c4 (zero padded to 16 columns), so a
+//   B fragment is one coalesced 16-byte load per lane (256 B per lane group).
+//   S > 1: the unit list is cut into S contiguous chunks (blockIdx.z), partial sums go to a slab and
+//   k_reduce_epilogue adds them in fixed order (bit-reproducible, no atomics).
+template <int NTW, bool CIN1>
+__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+  __shared__ unsigned char klist[4][128];
   const int count = *a.n_out;
+  const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int upk = a.cin >> 2;
-  const int total_units = a.K * upk;
-  const int groups = (total_units + 3) >> 2;
-  for (int tile = blockIdx.x; tile * 64 < count; tile += gridDim.x) {
-    const int row0 = tile * 64 + wave * 16;
-    if (row0 >= count) continue;
+  const int nt0 = blockIdx.y * NTW;
+  const int split = blockIdx.z;
+  unsigned char *kl = klist[wave];
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
     const int row = row0 + r;
     const bool rvalid = row < count;
-    floatx4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // ---- prologue: compact list of present offsets (wave-synchronous LDS)
+    int nk = 1;
+    __builtin_amdgcn_wave_barrier();
+    if (a.tmask) {
+      const uint32_t *m = a.tmask + (size_t)tile * 4;
+      const uint32_t w0 = m[lane >> 5], w1 = m[2 + (lane >> 5)];
+      const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = (w1 >> (lane & 31)) & 1u;
+      const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const int n0 = __popcll(bal0);
+      if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)lane;
+      if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(lane + 64);
+      nk = n0 + __popcll(bal1);
+    } else if (lane == 0) {
+      kl[0] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int U = CIN1 ? nk : nk * a.upk;
+    int per = (U + a.S - 1) / a.S;
+    per = (per + 3) & ~3;
+    const int j0 = split * per;
+    const int j1 = min(U, j0 + per);
 
-    for (int g = 0; g < groups; ++g) {
-      const int u = 4 * g + q;
-      const bool uvalid = u < total_units;
-      int idx = -1, c4 = 0;
-      if (rvalid && uvalid) {
-        const int k = u / upk;
-        c4 = u - k * upk;
-        idx = a.nbr ? a.nbr[(size_t)k * a.ldn + row] : row;
-      }
-      if (__ballot(idx >= 0) == 0ull) continue;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx >= 0) v = *reinterpret_cast<const float4 *>(a.in + (size_t)idx * a.ldi + 4 * c4);
-      const float av[4] = {v.x, v.y, v.z, v.w};
-      const float *wrow = a.W + (size_t)(4 * u) * a.cout;
+    floatx4 acc[NTW];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 2
+    for (int jb = j0; jb < j1; jb += 4) {
+      const int j = jb + q;
+      const bool valid = j < j1;
+      if (CIN1) {
+        const int k = valid ? (int)kl[j] : 0;
+        int idx = -1;
+        if (valid && rvalid) idx = a.nbr[(size_t)k * a.ldn + row];
+        float av = 0.f;
+        if (idx >= 0) av = a.in ? a.in[(size_t)idx * a.ldi] : a.in_const;
+        const float bv = valid ? a.Wu[k * 16 + r] : 0.f;
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[0], 0, 0, 0);
+      } else {
+        const int kk = valid ? (int)(((float)j + 0.5f) * a.inv_upk) : 0;
+        const int c4 = valid ? j - kk * a.upk : 0;
+        const int k = (int)kl[kk];
+        int idx = -1;
+        if (valid && rvalid) idx = a.nbr ? a.nbr[(size_t)k * a.ldn + row] : row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx >= 0) v = *reinterpret_cast<const float4 *>(a.in + (size_t)idx * a.ldi + 4 * c4);
+        const float4 *wp = reinterpret_cast<const float4 *>(a.Wu) + ((size_t)(k * a.upk + c4) * a.NT + nt0) * 16 + r;
+        float4 b[NTW];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          const int col = nt * 16 + r;
-          const float bv = (uvalid && col < a.cout) ? wrow[s * a.cout + col] : 0.f;
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) b[nt] = valid ? wp[nt * 16] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, b[nt].x, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, b[nt].y, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, b[nt].z, acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, b[nt].w, acc[nt], 0, 0, 0);
         }
       }
     }
-    // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+    // ---- epilogue.  C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = nt * 16 + r;
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = (nt0 + nt) * 16 + r;
       if (col >= a.cout) continue;
+      if (a.S > 1) {
+        float *sl = a.slab + (size_t)split * a.slab_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ro = row0 + q * 4 + i;
+          if (ro < count) sl[(size_t)ro * a.cout + col] = acc[nt][i];
+        }
+        continue;
+      }
       const float sc = a.scale[col], sh = a.shift[col];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -404,41 +467,18 @@ __global__ __launch_bounds__(256) void k_conv_mfma(ConvArgs a) {
   }
 }
 
-// cin == 1 (conv0p1s1, 5x5x5x1): the GEMM K dimension is the kernel offset itself.
-__global__ __launch_bounds__(256) void k_conv_cin1(ConvArgs a) {
+// split-K tail: out = epilogue(sum_s slab[s]) with s ascending (deterministic).
+__global__ void k_reduce_epilogue(ConvArgs a) {
   const int count = *a.n_out;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const int groups = (a.K + 3) >> 2;
-  for (int tile = blockIdx.x; tile * 64 < count; tile += gridDim.x) {
-    const int row0 = tile * 64 + wave * 16;
-    if (row0 >= count) continue;
-    const int row = row0 + r;
-    const bool rvalid = row < count;
-    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
-    for (int g = 0; g < groups; ++g) {
-      const int k = 4 * g + q;
-      const bool kvalid = k < a.K;
-      int idx = -1;
-      if (rvalid && kvalid) idx = a.nbr ? a.nbr[(size_t)k * a.ldn + row] : row;
-      if (__ballot(idx >= 0) == 0ull) continue;
-      float av = 0.f;
-      if (idx >= 0) av = a.in ? a.in[(size_t)idx * a.ldi] : a.in_const;
-      const float bv = (kvalid && r < a.cout) ? a.W[(size_t)k * a.cout + r] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-    }
-    if (r < a.cout) {
-      const float sc = a.scale[r], sh = a.shift[r];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ro = row0 + q * 4 + i;
-        if (ro >= count) continue;
-        float y = acc[i] * sc + sh;
-        if (a.res) y += a.res[(size_t)ro * a.ldr + r];
-        if (a.relu) y = fmaxf(y, 0.f);
-        a.out[(size_t)ro * a.ldo + r] = y;
-      }
-    }
+  const int64_t total = (int64_t)count * a.cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ro = (int)(i / a.cout), col = (int)(i - (int64_t)ro * a.cout);
+    float sum = 0.f;
+    for (int s = 0; s < a.S; ++s) sum += a.slab[(size_t)s * a.slab_stride + i];
+    float y = sum * a.scale[col] + a.shift[col];
+    if (a.res) y += a.res[(size_t)ro * a.ldr + col];
+    if (a.relu) y = fmaxf(y, 0.f);
+    a.out[(size_t)ro * a.ldo + col] = y;
   }
 }
 
@@ -454,7 +494,7 @@ __global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__r
 // ------------------------------------------------------------------------------------------
 // metrics (models.py:84-105, util.py:285-299): per batch index accumulators over scan rows
 // ------------------------------------------------------------------------------------------
-__global__ void k_metrics(const float *__restrict__ scores, const float *__restrict__ batch, int64_t ld, int n,
+__global__ __launch_bounds__(256) void k_metrics(const float *__restrict__ scores, const float *__restrict__ batch, int64_t ld, int n,
                           float eps, int n_batches, double *__restrict__ acc) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -479,16 +519,34 @@ __global__ void k_metrics(const float *__restrict__ scores, const float *__restr
       }
     }
   }
-  // wave-level reduction when every contributing lane shares one batch index (the common case)
-  int bref = b;
-  for (int o = 32; o > 0; o >>= 1) bref = max(bref, __shfl_xor(bref, o, 64));
-  if (bref < 0) return;  // wave-uniform
-  if (__all(b == bref || b < 0)) {
+  // block-level reduction when every contributing lane of the block shares one batch index (the
+  // common case: rows are grouped by b); one atomic per block and accumulator.
+  __shared__ double red[8][4];
+  __shared__ int bmin_s, bmax_s;
+  if (threadIdx.x == 0) {
+    bmin_s = 0x7fffffff;
+    bmax_s = -1;
+  }
+  __syncthreads();
+  if (b >= 0) {
+    atomicMin(&bmin_s, b);
+    atomicMax(&bmax_s, b);
+  }
+  __syncthreads();
+  const int bmin = bmin_s, bmax = bmax_s;
+  if (bmax < 0) return;  // block-uniform
+  if (bmin == bmax) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       double x = v[j];
       for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
-      if ((threadIdx.x & 63) == 0 && x != 0.0) atomicAdd(&acc[bref * 8 + j], x);
+      if (lane == 0) red[j][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const double x = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+      if (x != 0.0) atomicAdd(&acc[bmax * 8 + threadIdx.x], x);
     }
   } else if (b >= 0) {
 #pragma unroll
@@ -652,6 +710,10 @@ struct ConvSpec {
   int K, cin, cout;
   int64_t w_off = 0;   // offset of the kernel in the blob (floats)
   int64_t ss_off = 0;  // offset of scale/shift pair in the derived buffer
+  int64_t wu_off = 0;  // offset of the unit-major permuted kernel (floats)
+  int nt() const { return (cout + 15) / 16; }
+  int upk() const { return cin / 4; }
+  int64_t wu_numel() const { return cin == 1 ? (int64_t)K * 16 : (int64_t)K * upk() * nt() * 64; }
 };
 struct BnSpec {
   std::string name;
@@ -667,7 +729,7 @@ struct NetSpec {
   std::vector<ConvSpec> convs;
   std::vector<BnSpec> bns;
   std::vector<TensorInfo> tensors;
-  int64_t numel = 0, ss_numel = 0, bias_off = 0;
+  int64_t numel = 0, ss_numel = 0, bias_off = 0, wu_numel = 0;
   int find_conv(const std::string &n) const {
     for (size_t i = 0; i < convs.size(); ++i)
       if (convs[i].name == n) return (int)i;
@@ -713,8 +775,10 @@ NetSpec build_spec() {
   }
   s.convs.push_back({"final", "", 1, PLANES[7], 1});
   // blob layout: conv kernels, then BN (weight,bias,mean,var), then final.bias
-  int64_t off = 0, ss = 0;
+  int64_t off = 0, ss = 0, wu = 0;
   for (auto &c : s.convs) {
+    c.wu_off = wu;
+    wu += c.wu_numel();
     c.w_off = off;
     const int64_t n = (int64_t)c.K * c.cin * c.cout;
     s.tensors.push_back({c.name + ".kernel", off, n});
@@ -735,6 +799,7 @@ NetSpec build_spec() {
   off += 1;
   s.numel = off;
   s.ss_numel = ss;
+  s.wu_numel = wu;
   return s;
 }
 
@@ -746,6 +811,8 @@ const NetSpec &spec() {
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
+constexpr int MAX_SPLIT = 8;
+
 inline int64_t next_pow2(int64_t v) {
   int64_t p = 1;
   while (p < v) p <<= 1;
@@ -761,6 +828,7 @@ struct Level {
   int *nbr3 = nullptr;         // [81][cap]
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
   int *up = nullptr;           // [8][cap]  (levels 1..4) indexed by level-1 voxel
+  uint32_t *tm3 = nullptr, *tmdown = nullptr, *tmup = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
 };
 
 struct Feat {
@@ -788,6 +856,11 @@ struct sps_ctx {
   unsigned long long *pairs = nullptr;  // [128]
   float *blob = nullptr;     // weights
   float *ss = nullptr;       // folded scale/shift
+  float *wu = nullptr;       // unit-major permuted conv kernels (k_conv B operand)
+  uint32_t *tmask_all = nullptr, *tm5 = nullptr;  // all tile masks (one memset per forward)
+  size_t tmask_bytes = 0;
+  float *slab = nullptr;     // split-K partial sums
+  int64_t slab_stride = 0;
   // feature buffers
   float *cat8 = nullptr, *b8t = nullptr, *b8r = nullptr, *b8o = nullptr, *logits = nullptr;
   float *x1 = nullptr, *b1t = nullptr, *cat7 = nullptr, *b7t = nullptr, *b7r = nullptr, *b7o = nullptr;
@@ -854,6 +927,26 @@ int reserve(sps_ctx *c, int64_t n) {
     }
   }
   ALLOC(c->nbr5, int, 125 * cap);
+  {
+    const size_t tm_words = (size_t)(cap / 16) * 4;  // cap is a multiple of 1024
+    ALLOC(c->tmask_all, uint32_t, tm_words * 14);
+    c->tmask_bytes = tm_words * 14 * sizeof(uint32_t);
+    uint32_t *p = c->tmask_all;
+    c->tm5 = p;
+    p += tm_words;
+    for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+      c->lv[l].tm3 = p;
+      p += tm_words;
+      if (l > 0) {
+        c->lv[l].tmdown = p;
+        p += tm_words;
+        c->lv[l].tmup = p;
+        p += tm_words;
+      }
+    }
+  }
+  c->slab_stride = cap * 64;
+  ALLOC(c->slab, float, (size_t)MAX_SPLIT * c->slab_stride);
   ALLOC(c->block_sums, int, cap / SCAN_BLOCK + 8);
   ALLOC(c->keep, int, cap);
   ALLOC(c->cat8, float, 16 * cap);
@@ -913,20 +1006,10 @@ int rank_level(sps_ctx *c, Level &L, const int *n_ptr, int n_fixed, int64_t n_bo
   return SPS_OK;
 }
 
-void launch_conv(sps_ctx *c, const ConvArgs &a, hipStream_t st) {
-  const int g = grid_for(c->cap, 64, 4096);
-  if (a.cin == 1) {
-    hipLaunchKernelGGL(k_conv_cin1, dim3(g), dim3(256), 0, st, a);
-    return;
-  }
-  const int nt = (a.cout + 15) / 16;
-  if (nt == 1)
-    hipLaunchKernelGGL(k_conv_mfma<1>, dim3(g), dim3(256), 0, st, a);
-  else if (nt == 2)
-    hipLaunchKernelGGL(k_conv_mfma<2>, dim3(g), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(k_conv_mfma<4>, dim3(g), dim3(256), 0, st, a);
-}
+struct Map {
+  const int *nbr;
+  const uint32_t *tmask;
+};
 
 struct ConvCall {
   const char *name;
@@ -934,12 +1017,30 @@ struct ConvCall {
   int ldi;
   float *out;
   int ldo;
-  const int *nbr;
+  Map map;
   int level_out;
   const float *res;
   int ldr;
   int relu;
 };
+
+// Launch geometry per output level (config-2 sizes: 108k / 43k / 15k / 5k / 1.7k rows).  The fine
+// levels have thousands of 16-row tiles; the coarse ones need split-N (one 16-column tile per wave)
+// and split-K to put enough waves on 256 CUs.  Correctness never depends on these numbers: the
+// kernels grid-stride over the real (device-side) row count.
+struct Geometry {
+  int ntw, S;
+};
+Geometry conv_geometry(int level, int K, int cin, int nt) {
+  if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
+  switch (level) {
+    case 0: return {nt, 1};
+    case 1: return {nt, 1};
+    case 2: return {1, 2};
+    case 3: return {1, 4};
+    default: return {1, 8};
+  }
+}
 
 int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   const NetSpec &s = spec();
@@ -951,21 +1052,64 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.ldi = cc.ldi;
   a.out = cc.out;
   a.ldo = cc.ldo;
-  a.W = c->blob + cs.w_off;
+  a.Wu = c->wu + cs.wu_off;
   a.scale = c->ss + cs.ss_off;
   a.shift = c->ss + cs.ss_off + cs.cout;
   a.res = cc.res;
   a.ldr = cc.ldr;
-  a.nbr = cc.nbr;
+  a.nbr = cc.map.nbr;
+  a.tmask = cc.map.tmask;
   a.ldn = c->cap;
   a.n_out = c->counts + cc.level_out;
   a.K = cs.K;
   a.cin = cs.cin;
   a.cout = cs.cout;
+  a.NT = cs.nt();
+  a.upk = cs.upk();
+  a.inv_upk = cs.cin >= 4 ? 1.0f / (float)cs.upk() : 1.f;
   a.relu = cc.relu;
   a.in_const = 0.5f;  // models.py:22
-  launch_conv(c, a, st);
+  a.slab = c->slab;
+  a.slab_stride = c->slab_stride;
+  const Geometry g = conv_geometry(cc.level_out, cs.K, cs.cin, a.NT);
+  a.S = g.S;
+  // expected tiles at this level (rows shrink ~2.5x per level); floor keeps small clouds parallel
+  int64_t gx = (c->cap / 64) >> cc.level_out;
+  if (gx < 64) gx = 64;
+  if (gx > 4096) gx = 4096;
+  const dim3 grid((unsigned)gx, (unsigned)(a.NT / g.ntw), (unsigned)g.S);
+  if (cs.cin == 1)
+    hipLaunchKernelGGL((k_conv<1, true>), grid, dim3(256), 0, st, a);
+  else if (g.ntw == 1)
+    hipLaunchKernelGGL((k_conv<1, false>), grid, dim3(256), 0, st, a);
+  else if (g.ntw == 2)
+    hipLaunchKernelGGL((k_conv<2, false>), grid, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((k_conv<4, false>), grid, dim3(256), 0, st, a);
+  if (g.S > 1) hipLaunchKernelGGL(k_reduce_epilogue, dim3((unsigned)(gx < 256 ? gx : 256)), dim3(256), 0, st, a);
   return SPS_OK;
+}
+
+// Host-side permutation of one kernel [K][cin][cout] into the unit-major MFMA B-fragment order
+// Wu[u][nt][n][s] = W[k][4*c4 + s][16*nt + n], u = k*upk + c4 (columns zero padded to 16*NT).
+void permute_weights(const ConvSpec &cs, const float *W, float *Wu) {
+  if (cs.cin == 1) {
+    for (int k = 0; k < cs.K; ++k)
+      for (int n = 0; n < 16; ++n) Wu[k * 16 + n] = n < cs.cout ? W[(size_t)k * cs.cout + n] : 0.f;
+    return;
+  }
+  const int upk = cs.upk(), NT = cs.nt();
+  for (int k = 0; k < cs.K; ++k)
+    for (int c4 = 0; c4 < upk; ++c4) {
+      const int u = k * upk + c4;
+      for (int nt = 0; nt < NT; ++nt)
+        for (int n = 0; n < 16; ++n)
+          for (int sidx = 0; sidx < 4; ++sidx) {
+            const int col = nt * 16 + n;
+            const float v = col < cs.cout ? W[((size_t)k * cs.cin + 4 * c4 + sidx) * cs.cout + col] : 0.f;
+            Wu[(((size_t)u * NT + nt) * 16 + n) * 4 + sidx] = v;
+          }
+    }
 }
 
 // records an event that closes the stage `name` (profiling mode only)
@@ -1015,6 +1159,7 @@ int sps_ctx_create(int device, sps_ctx **out) {
   HIP_TRY(hipMalloc((void **)&c->pairs, 128 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc((void **)&c->blob, s.numel * sizeof(float)));
   HIP_TRY(hipMalloc((void **)&c->ss, s.ss_numel * sizeof(float)));
+  HIP_TRY(hipMalloc((void **)&c->wu, s.wu_numel * sizeof(float)));
   HIP_TRY(hipMemset(c->counts, 0, 8 * sizeof(int)));
   HIP_TRY(hipMemset(c->err, 0, sizeof(int)));
   *out = c;
@@ -1032,6 +1177,7 @@ int sps_ctx_destroy(sps_ctx *c) {
   (void)hipFree(c->pairs);
   (void)hipFree(c->blob);
   (void)hipFree(c->ss);
+  (void)hipFree(c->wu);
   if (c->map_keys_alloc) (void)hipFree(c->map_keys_alloc);
   delete c;
   return SPS_OK;
@@ -1085,6 +1231,9 @@ int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) {
       sh[j] = (float)((double)bi[j] - (double)mu[j] * scale);
     }
   }
+  std::vector<float> wu((size_t)s.wu_numel);
+  for (const ConvSpec &cs : s.convs) permute_weights(cs, blob + cs.w_off, wu.data() + cs.wu_off);
+  HIP_TRY(hipMemcpy(c->wu, wu.data(), wu.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->blob, blob, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
   c->have_weights = true;
@@ -1113,6 +1262,7 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
     HIP_TRY(hipMemsetAsync(c->lv[l].h.first, 0x7F, (size_t)c->hcap * sizeof(int), st));
   }
   HIP_TRY(hipMemsetAsync(c->counts, 0, 5 * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(c->tmask_all, 0, c->tmask_bytes, st));
   if (n == 0) return SPS_OK;
   prof_mark(c, "reset", st);
 
@@ -1134,56 +1284,57 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   // ---- kernel maps
   const int gx = grid_for(cap, 256, 1024);
   hipLaunchKernelGGL(k_build_nbr<NBR_5551>, dim3(gx, 125), dim3(256), 0, st, L0.vkeys, c->counts + 0, 1, L0.h,
-                     c->nbr5, cap);
+                     c->nbr5, cap, c->tm5);
   for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
     Level &L = c->lv[l];
     hipLaunchKernelGGL(k_build_nbr<NBR_3333>, dim3(gx, 81), dim3(256), 0, st, L.vkeys, c->counts + l, 1 << l, L.h,
-                       L.nbr3, cap);
+                       L.nbr3, cap, L.tm3);
   }
   for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
     Level &F = c->lv[l - 1], &L = c->lv[l];
     const int ts = 1 << (l - 1);
     hipLaunchKernelGGL(k_build_nbr<NBR_DOWN>, dim3(gx, 8), dim3(256), 0, st, L.vkeys, c->counts + l, ts, F.h, L.down,
-                       cap);
-    hipLaunchKernelGGL(k_build_up, dim3(gx), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts, L.inv, L.up, cap);
+                       cap, L.tmdown);
+    hipLaunchKernelGGL(k_build_up, dim3(gx), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts, L.inv, L.up, cap,
+                       L.tmup);
   }
   prof_mark(c, "maps", st);
   // ---- network (minkunet.py:161-219)
   Level *lv = c->lv;
   const ConvCall calls[] = {
-      {"conv0p1s1", nullptr, 1, c->cat8 + 8, 16, c->nbr5, 0, nullptr, 0, 1},
-      {"conv1p1s2", c->cat8 + 8, 16, c->x1, 8, lv[1].down, 1, nullptr, 0, 1},
-      {"block1.0.conv1", c->x1, 8, c->b1t, 8, lv[1].nbr3, 1, nullptr, 0, 1},
-      {"block1.0.conv2", c->b1t, 8, c->cat7 + 16, 24, lv[1].nbr3, 1, c->x1, 8, 1},
-      {"conv2p2s2", c->cat7 + 16, 24, c->x2, 8, lv[2].down, 2, nullptr, 0, 1},
-      {"block2.0.conv1", c->x2, 8, c->b2t, 16, lv[2].nbr3, 2, nullptr, 0, 1},
-      {"block2.0.downsample.0", c->x2, 8, c->b2r, 16, nullptr, 2, nullptr, 0, 0},
-      {"block2.0.conv2", c->b2t, 16, c->cat6 + 32, 48, lv[2].nbr3, 2, c->b2r, 16, 1},
-      {"conv3p4s2", c->cat6 + 32, 48, c->x3, 16, lv[3].down, 3, nullptr, 0, 1},
-      {"block3.0.conv1", c->x3, 16, c->b3t, 32, lv[3].nbr3, 3, nullptr, 0, 1},
-      {"block3.0.downsample.0", c->x3, 16, c->b3r, 32, nullptr, 3, nullptr, 0, 0},
-      {"block3.0.conv2", c->b3t, 32, c->cat5 + 64, 96, lv[3].nbr3, 3, c->b3r, 32, 1},
-      {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, lv[4].down, 4, nullptr, 0, 1},
-      {"block4.0.conv1", c->x4, 32, c->b4t, 64, lv[4].nbr3, 4, nullptr, 0, 1},
-      {"block4.0.downsample.0", c->x4, 32, c->b4r, 64, nullptr, 4, nullptr, 0, 0},
-      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, lv[4].nbr3, 4, c->b4r, 64, 1},
-      {"convtr4p16s2", c->b4o, 64, c->cat5, 96, lv[4].up, 3, nullptr, 0, 1},
-      {"block5.0.conv1", c->cat5, 96, c->b5t, 64, lv[3].nbr3, 3, nullptr, 0, 1},
-      {"block5.0.downsample.0", c->cat5, 96, c->b5r, 64, nullptr, 3, nullptr, 0, 0},
-      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, lv[3].nbr3, 3, c->b5r, 64, 1},
-      {"convtr5p8s2", c->b5o, 64, c->cat6, 48, lv[3].up, 2, nullptr, 0, 1},
-      {"block6.0.conv1", c->cat6, 48, c->b6t, 32, lv[2].nbr3, 2, nullptr, 0, 1},
-      {"block6.0.downsample.0", c->cat6, 48, c->b6r, 32, nullptr, 2, nullptr, 0, 0},
-      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, lv[2].nbr3, 2, c->b6r, 32, 1},
-      {"convtr6p4s2", c->b6o, 32, c->cat7, 24, lv[2].up, 1, nullptr, 0, 1},
-      {"block7.0.conv1", c->cat7, 24, c->b7t, 16, lv[1].nbr3, 1, nullptr, 0, 1},
-      {"block7.0.downsample.0", c->cat7, 24, c->b7r, 16, nullptr, 1, nullptr, 0, 0},
-      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, lv[1].nbr3, 1, c->b7r, 16, 1},
-      {"convtr7p2s2", c->b7o, 16, c->cat8, 16, lv[1].up, 0, nullptr, 0, 1},
-      {"block8.0.conv1", c->cat8, 16, c->b8t, 8, lv[0].nbr3, 0, nullptr, 0, 1},
-      {"block8.0.downsample.0", c->cat8, 16, c->b8r, 8, nullptr, 0, nullptr, 0, 0},
-      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, lv[0].nbr3, 0, c->b8r, 8, 1},
-      {"final", c->b8o, 8, c->logits, 1, nullptr, 0, nullptr, 0, 0},
+      {"conv0p1s1", nullptr, 1, c->cat8 + 8, 16, Map{c->nbr5, c->tm5}, 0, nullptr, 0, 1},
+      {"conv1p1s2", c->cat8 + 8, 16, c->x1, 8, Map{lv[1].down, lv[1].tmdown}, 1, nullptr, 0, 1},
+      {"block1.0.conv1", c->x1, 8, c->b1t, 8, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1},
+      {"block1.0.conv2", c->b1t, 8, c->cat7 + 16, 24, Map{lv[1].nbr3, lv[1].tm3}, 1, c->x1, 8, 1},
+      {"conv2p2s2", c->cat7 + 16, 24, c->x2, 8, Map{lv[2].down, lv[2].tmdown}, 2, nullptr, 0, 1},
+      {"block2.0.conv1", c->x2, 8, c->b2t, 16, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
+      {"block2.0.downsample.0", c->x2, 8, c->b2r, 16, Map{nullptr, nullptr}, 2, nullptr, 0, 0},
+      {"block2.0.conv2", c->b2t, 16, c->cat6 + 32, 48, Map{lv[2].nbr3, lv[2].tm3}, 2, c->b2r, 16, 1},
+      {"conv3p4s2", c->cat6 + 32, 48, c->x3, 16, Map{lv[3].down, lv[3].tmdown}, 3, nullptr, 0, 1},
+      {"block3.0.conv1", c->x3, 16, c->b3t, 32, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
+      {"block3.0.downsample.0", c->x3, 16, c->b3r, 32, Map{nullptr, nullptr}, 3, nullptr, 0, 0},
+      {"block3.0.conv2", c->b3t, 32, c->cat5 + 64, 96, Map{lv[3].nbr3, lv[3].tm3}, 3, c->b3r, 32, 1},
+      {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, Map{lv[4].down, lv[4].tmdown}, 4, nullptr, 0, 1},
+      {"block4.0.conv1", c->x4, 32, c->b4t, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1},
+      {"block4.0.downsample.0", c->x4, 32, c->b4r, 64, Map{nullptr, nullptr}, 4, nullptr, 0, 0},
+      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, c->b4r, 64, 1},
+      {"convtr4p16s2", c->b4o, 64, c->cat5, 96, Map{lv[4].up, lv[4].tmup}, 3, nullptr, 0, 1},
+      {"block5.0.conv1", c->cat5, 96, c->b5t, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
+      {"block5.0.downsample.0", c->cat5, 96, c->b5r, 64, Map{nullptr, nullptr}, 3, nullptr, 0, 0},
+      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, c->b5r, 64, 1},
+      {"convtr5p8s2", c->b5o, 64, c->cat6, 48, Map{lv[3].up, lv[3].tmup}, 2, nullptr, 0, 1},
+      {"block6.0.conv1", c->cat6, 48, c->b6t, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
+      {"block6.0.downsample.0", c->cat6, 48, c->b6r, 32, Map{nullptr, nullptr}, 2, nullptr, 0, 0},
+      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, c->b6r, 32, 1},
+      {"convtr6p4s2", c->b6o, 32, c->cat7, 24, Map{lv[2].up, lv[2].tmup}, 1, nullptr, 0, 1},
+      {"block7.0.conv1", c->cat7, 24, c->b7t, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1},
+      {"block7.0.downsample.0", c->cat7, 24, c->b7r, 16, Map{nullptr, nullptr}, 1, nullptr, 0, 0},
+      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, c->b7r, 16, 1},
+      {"convtr7p2s2", c->b7o, 16, c->cat8, 16, Map{lv[1].up, lv[1].tmup}, 0, nullptr, 0, 1},
+      {"block8.0.conv1", c->cat8, 16, c->b8t, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1},
+      {"block8.0.downsample.0", c->cat8, 16, c->b8r, 8, Map{nullptr, nullptr}, 0, nullptr, 0, 0},
+      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, c->b8r, 8, 1},
+      {"final", c->b8o, 8, c->logits, 1, Map{nullptr, nullptr}, 0, nullptr, 0, 0},
   };
   for (const ConvCall &cc : calls) {
     int rc = run_conv(c, cc, st);

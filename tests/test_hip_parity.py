@@ -136,10 +136,12 @@ def test_batch_independence(net, params):
         stacked.append(q)
     big = np.concatenate(stacked, 0)
     dev, s = run(net, big)
-    np.testing.assert_array_equal(s.cpu().numpy(), np.concatenate(singles))   # bit-exact: same sums
+    # same terms per row; only the f32 summation grouping may differ with the tile composition
+    np.testing.assert_allclose(s.cpu().numpy(), np.concatenate(singles), rtol=0, atol=2e-6)
     per = net.step_metrics(dev, s, n_batches=3)
     for i, p in enumerate(parts):
-        mo = O.predict_metrics(singles[i], p, EPS)
+        sb = s.cpu().numpy()[sum(len(q) for q in parts[:i]): sum(len(q) for q in parts[:i + 1])]
+        mo = O.predict_metrics(sb, p, EPS)
         from sps_amd.models.models import metrics_from_sums
         assert metrics_from_sums(per[i])["dIoU"] == pytest.approx(mo["dIoU"], abs=1e-12, nan_ok=True)
 
@@ -150,11 +152,21 @@ def test_permutation_and_duplicates(net, params):
     rng = np.random.default_rng(0)
     perm = rng.permutation(len(batch))
     _, s1 = run(net, batch[perm])
-    np.testing.assert_array_equal(s1.cpu().numpy(), s0.cpu().numpy()[perm])   # order-free, bit-exact
+    np.testing.assert_allclose(s1.cpu().numpy(), s0.cpu().numpy()[perm], rtol=0, atol=2e-6)   # order-free
     dup = np.concatenate([batch, batch[:300]], 0)
     _, s2 = run(net, dup)
-    np.testing.assert_array_equal(s2.cpu().numpy()[: len(batch)], s0.cpu().numpy())
+    np.testing.assert_array_equal(s2.cpu().numpy()[: len(batch)], s0.cpu().numpy())     # same voxel rows
     np.testing.assert_array_equal(s2.cpu().numpy()[len(batch):], s0.cpu().numpy()[:300])
+
+
+def test_run_to_run_determinism(net, params):
+    """No atomics in any floating-point sum: the same input gives the same bits, every time."""
+    batch = synthetic.small_scene(seed=31, n_scan=3000)
+    _, a = run(net, batch)
+    a = a.cpu().numpy().copy()
+    for _ in range(3):
+        _, b = run(net, batch)
+        np.testing.assert_array_equal(b.cpu().numpy(), a)
 
 
 def test_edge_cases(net, params):
