@@ -44,6 +44,7 @@ extern "C" {
 #define SPS_T_MIN (-16)
 #define SPS_T_MAX (15)
 #define SPS_BATCH_MAX (30)
+#define SPS_MAX_POINTS (1 << 24) /* rows per forward / submap call */
 
 typedef struct sps_ctx sps_ctx;
 

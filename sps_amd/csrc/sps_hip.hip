@@ -121,48 +121,171 @@ __device__ inline int hash_lookup(const HashTable &h, uint64_t key) {
 }
 
 // ------------------------------------------------------------------------------------------
-// voxelisation kernels
+// block-sparse voxel grid
+//
+// Every tensor stride (level l, stride 2^l) keeps its active voxels as 4x4x4 BLOCKS (in units of
+// the level's stride) with a 64-bit occupancy mask:
+//   block key  u64  [b:5 | t+16:5 | BZ:18 | BY:18 | BX:18],  BX = (x + 2^17) >> (l + 2)
+//   bit        = (pz << 4) | (py << 2) | px,   p = ((x + 2^17) >> l) & 3
+// Blocks are ranked in first-occurrence order (deterministic); voxel rows are block-contiguous:
+//   row(voxel) = bbase[block] + popcount(mask & below(bit))
+// so that (a) the rows of a 16-row convolution tile are spatial neighbours, (b) a coarser level is
+// derived from the finer level's block masks alone (one thread per BLOCK, no per-voxel hashing), and
+// (c) a neighbour lookup is "adjacent block (precomputed per block) + mask test + popcount": the hash
+// is probed 81 times per block instead of 81..125 times per voxel.
 // ------------------------------------------------------------------------------------------
 constexpr int SCAN_BLOCK = 1024;
 
-// level 0: quantise points (models.py:21: f32 true division by [1,vs,vs,vs,1]; ME floor) and insert.
-__global__ void k_points_insert(const float *__restrict__ coords, int64_t ld, int n, float vs, HashTable h,
-                                uint64_t *__restrict__ srckey, int *__restrict__ pslot, int *err) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const float *c = coords + (size_t)p * ld;
-  const float fb = floorf(__fdiv_rn(c[0], 1.0f));
-  const float fx = floorf(__fdiv_rn(c[1], vs));
-  const float fy = floorf(__fdiv_rn(c[2], vs));
-  const float fz = floorf(__fdiv_rn(c[3], vs));
-  const float ft = floorf(__fdiv_rn(c[4], 1.0f));
-  // compare in float first so that huge / NaN values cannot overflow the int conversion
-  const bool ok = fb >= 0.f && fb <= (float)SPS_BATCH_MAX && ft >= (float)SPS_T_MIN && ft <= (float)SPS_T_MAX &&
-                  fx >= (float)SPS_COORD_MIN && fx <= (float)SPS_COORD_MAX && fy >= (float)SPS_COORD_MIN &&
-                  fy <= (float)SPS_COORD_MAX && fz >= (float)SPS_COORD_MIN && fz <= (float)SPS_COORD_MAX;
-  if (!ok) {
-    atomicOr(err, 1);
-    srckey[p] = KEY_EMPTY;
-    pslot[p] = -1;
-    return;
+struct BHash {
+  uint64_t *keys;            // KEY_EMPTY when free
+  unsigned long long *mask;  // occupancy of the block
+  int *first;                // smallest source index that touched the block
+  int *rank;                 // block rank (first-occurrence order)
+  uint32_t *occ;             // 1 bit per slot: "slot in use" -- a cache-resident filter in front of keys[]
+  uint32_t hmask;
+};
+
+__device__ inline int bhash_insert(const BHash &h, uint64_t key) {
+  uint32_t s = hash64(key) & h.hmask;
+  while (true) {
+    unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[s]),
+                                        (unsigned long long)KEY_EMPTY, (unsigned long long)key);
+    if (prev == KEY_EMPTY) atomicOr(&h.occ[s >> 5], 1u << (s & 31));
+    if (prev == KEY_EMPTY || prev == key) return (int)s;
+    s = (s + 1) & h.hmask;
   }
-  const uint64_t key = key_pack((int)fb, (int)fx, (int)fy, (int)fz, (int)ft);
-  const int s = hash_insert(h, key);
-  atomicMin(&h.first[s], p);
-  srckey[p] = key;
-  pslot[p] = s;
+}
+// Lookups run in later launches than the inserts.  Most probes of the adjacency build miss: the
+// occupancy bitmap (hcap/8 bytes, L2-resident) answers them without touching the 8-byte key array.
+__device__ inline int bhash_find(const BHash &h, uint64_t key) {
+  uint32_t s = hash64(key) & h.hmask;
+  while (true) {
+    if (!((h.occ[s >> 5] >> (s & 31)) & 1u)) return -1;
+    if (h.keys[s] == key) return (int)s;
+    s = (s + 1) & h.hmask;
+  }
 }
 
-// level l >= 1: parents of the finer level's voxels (App. A.9).
-__global__ void k_parent_insert(const uint64_t *__restrict__ fine_keys, const int *__restrict__ n_fine, int ts,
-                                HashTable h, uint64_t *__restrict__ srckey, int *__restrict__ pslot) {
-  const int n = *n_fine;
-  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-    const uint64_t key = key_parent(fine_keys[v], ts);
-    const int s = hash_insert(h, key);
-    atomicMin(&h.first[s], v);
-    srckey[v] = key;
-    pslot[v] = s;
+__device__ inline uint64_t bkey_pack(uint32_t b, uint32_t tt, uint32_t bx, uint32_t by, uint32_t bz) {
+  return ((uint64_t)b << 59) | ((uint64_t)tt << 54) | ((uint64_t)bz << 36) | ((uint64_t)by << 18) | (uint64_t)bx;
+}
+
+constexpr int NLV = SPS_NUM_LEVELS;
+
+// level 0: quantise points (models.py:21: f32 true division by [1,vs,vs,vs,1]; ME floor), insert the
+// point's block, set its occupancy bit.  Consecutive LiDAR returns mostly fall into the same block:
+// the wave elects one lane per distinct block, which issues the three atomics for the whole group.
+__global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restrict__ coords, int64_t ld, int n, float vs,
+                                                           BHash h, int *__restrict__ sslot,
+                                                           unsigned char *__restrict__ sbit, int *err) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  bool ok = false;
+  uint64_t key = KEY_EMPTY;
+  int bit = 0;
+  if (p < n) {
+    const float *c = coords + (size_t)p * ld;
+    const float fb = floorf(__fdiv_rn(c[0], 1.0f));
+    const float fx = floorf(__fdiv_rn(c[1], vs));
+    const float fy = floorf(__fdiv_rn(c[2], vs));
+    const float fz = floorf(__fdiv_rn(c[3], vs));
+    const float ft = floorf(__fdiv_rn(c[4], 1.0f));
+    // compare in float first so that huge / NaN values cannot overflow the int conversion
+    ok = fb >= 0.f && fb <= (float)SPS_BATCH_MAX && ft >= (float)SPS_T_MIN && ft <= (float)SPS_T_MAX &&
+         fx >= (float)SPS_COORD_MIN && fx <= (float)SPS_COORD_MAX && fy >= (float)SPS_COORD_MIN &&
+         fy <= (float)SPS_COORD_MAX && fz >= (float)SPS_COORD_MIN && fz <= (float)SPS_COORD_MAX;
+    if (ok) {
+      const uint32_t ux = (uint32_t)((int)fx + XBIAS), uy = (uint32_t)((int)fy + XBIAS), uz = (uint32_t)((int)fz + XBIAS);
+      key = bkey_pack((uint32_t)(int)fb, (uint32_t)((int)ft + TBIAS), ux >> 2, uy >> 2, uz >> 2);
+      bit = (int)(((uz & 3) << 4) | ((uy & 3) << 2) | (ux & 3));
+    } else {
+      atomicOr(err, 1);
+    }
+  }
+  // Runs of consecutive lanes with the same block: the first lane of a run issues the atomics for the
+  // whole run (segmented OR-scan over the run); all runs proceed in parallel.
+  const int lane = threadIdx.x & 63;
+  const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+  const uint32_t plo = __shfl_up(klo, 1, 64), phi = __shfl_up(khi, 1, 64);
+  const int pok = __shfl_up((int)ok, 1, 64);
+  const bool head = !(lane > 0 && ok && pok && plo == klo && phi == khi);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long le = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int rid = __popcll(le);
+  const int head_lane = 63 - __clzll((long long)le);
+  uint32_t olo = (ok && bit < 32) ? (1u << bit) : 0u, ohi = (ok && bit >= 32) ? (1u << (bit - 32)) : 0u;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t vlo = __shfl_down(olo, o, 64), vhi = __shfl_down(ohi, o, 64);
+    const int r2 = __shfl_down(rid, o, 64);
+    if (lane + o < 64 && r2 == rid) {
+      olo |= vlo;
+      ohi |= vhi;
+    }
+  }
+  int slot = -1;
+  if (head && ok) {
+    slot = bhash_insert(h, key);
+    atomicOr(&h.mask[slot], ((unsigned long long)ohi << 32) | olo);
+    atomicMin(&h.first[slot], p);  // the head is the run's smallest point index
+  }
+  slot = __shfl(slot, head_lane, 64);
+  if (p < n) {
+    sslot[p] = ok ? slot : -1;
+    sbit[p] = (unsigned char)bit;
+  }
+}
+
+// Per-level device arrays handed to the batched pyramid kernels (blockIdx.y = level index).
+struct PyramidArgs {
+  BHash h[NLV];
+  int *sslot[NLV];    // [l] hash slot (level l) of each SOURCE: points for l = 0, level-0 blocks for l >= 1
+  int *bslot[NLV];
+  uint64_t *bkey[NLV];
+  unsigned long long *bmask[NLV];
+  int *bbase[NLV];
+  int *bparent[NLV];
+  int *bchild[NLV];
+  int *badj[NLV];
+  int *vblock[NLV];
+  unsigned char *vbit[NLV];
+  int *counts;        // [0..4] voxels per level, [8..12] blocks per level
+  int *block_sums;    // scan scratch, `sums_stride` ints per level
+  int sums_stride;
+};
+
+// levels 1..4 in one pass: one thread per LEVEL-0 block inserts its ancestor block at every coarser
+// level (App. A.9: floor(c / 2ts) * 2ts applied l times = a right shift of the biased coordinate).
+// A level-0 block covers 2x2x2 level-1 voxels (an octant of its parent block) and exactly one voxel
+// of levels 2..4.
+__global__ void k_blocks_to_ancestors(PyramidArgs a) {
+  const int n = a.counts[8];
+  const int l = 1 + (int)blockIdx.y;
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const uint64_t key = a.bkey[0][r];
+    const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF),
+                   bz = (uint32_t)((key >> 36) & 0x3FFFF);
+    const uint64_t bt = key & (0x3FFull << 54);
+    const uint64_t pkey = bt | ((uint64_t)(bz >> l) << 36) | ((uint64_t)(by >> l) << 18) | (uint64_t)(bx >> l);
+    unsigned long long pm = 0;
+    if (l == 1) {
+      const unsigned long long m = a.bmask[0][r];
+      const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            if (m & (0x0000000000330033ull << (2 * i + 8 * j + 32 * k)))
+              pm |= 1ull << ((2 * oz + k) * 16 + (2 * oy + j) * 4 + (2 * ox + i));
+    } else {
+      const uint32_t px = (bx >> (l - 2)) & 3, py = (by >> (l - 2)) & 3, pz = (bz >> (l - 2)) & 3;
+      pm = 1ull << ((pz << 4) | (py << 2) | px);
+    }
+    const int s = bhash_insert(a.h[l], pkey);
+    atomicOr(&a.h[l].mask[s], pm);
+    atomicMin(&a.h[l].first[s], r);
+    a.sslot[l][r] = s;
   }
 }
 
@@ -178,141 +301,362 @@ __device__ inline int block_reduce_sum(int v, int *lds) {
   return tot;
 }
 
-// pass A: number of first occurrences per block of SCAN_BLOCK source elements.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(const int *__restrict__ pslot, const int *first,
-                                                             const int *__restrict__ n_ptr, int n_fixed,
-                                                             int *__restrict__ block_sums) {
-  __shared__ int lds[SCAN_BLOCK / 64];
-  const int n = n_ptr ? *n_ptr : n_fixed;
-  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  int flag = 0;
-  if (p < n) {
-    const int s = pslot[p];
-    flag = (s >= 0 && first[s] == p) ? 1 : 0;
-  }
-  const int tot = block_reduce_sum(flag, lds);
-  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-// pass B: exclusive scan of the first-occurrence flags -> voxel rows in first-occurrence order.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(const int *__restrict__ pslot, const int *first,
-                                                            const uint64_t *__restrict__ srckey,
-                                                            const int *__restrict__ n_ptr, int n_fixed,
-                                                            const int *__restrict__ block_sums, int *rank,
-                                                            uint64_t *__restrict__ vkeys, int *__restrict__ count_out) {
-  __shared__ int lds[SCAN_BLOCK / 64];
-  __shared__ int wave_off[SCAN_BLOCK / 64];
-  const int n = n_ptr ? *n_ptr : n_fixed;
-  const int nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  if ((int)blockIdx.x >= nblocks) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *count_out = 0;  // n == 0
-    return;
-  }
+// exclusive scan of `val` over the grid's elements given the per-workgroup totals of an earlier
+// pass: returns this thread's offset.
+__device__ inline int block_exclusive_scan(int val, const int *__restrict__ block_sums, int *lds, int *wave_off) {
   int part = 0;
   for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) part += block_sums[i];
   const int base = block_reduce_sum(part, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int incl = val;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_off[wave] = incl;
+  __syncthreads();
+  int off = 0;
+  for (int i = 0; i < wave; ++i) off += wave_off[i];
+  __syncthreads();
+  return base + off + incl - val;
+}
 
+// Batched over levels lv0 + blockIdx.y.  Sources of level 0 are the n0 points, of levels >= 1 the
+// level-0 blocks.
+// pass A: number of first occurrences per SCAN_BLOCK sources.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(PyramidArgs a, int lv0, int n0) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  const int l = lv0 + blockIdx.y;
+  const int n = l == 0 ? n0 : a.counts[8];
+  if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  int flag = 0;
+  if (p < n) {
+    const int s = a.sslot[l][p];
+    flag = (s >= 0 && a.h[l].first[s] == p) ? 1 : 0;
+  }
+  const int tot = block_reduce_sum(flag, lds);
+  if (threadIdx.x == 0) a.block_sums[l * a.sums_stride + blockIdx.x] = tot;
+}
+
+// pass B: rank of each block = exclusive scan of the flags; bslot[rank] = hash slot; block count.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv0, int n0) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int wave_off[SCAN_BLOCK / 64];
+  const int l = lv0 + blockIdx.y;
+  const int n = l == 0 ? n0 : a.counts[8];
+  const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  if ((int)blockIdx.x >= nwg) return;  // counts were zeroed by the reset
   const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   int s = -1, flag = 0;
   if (p < n) {
-    s = pslot[p];
-    flag = (s >= 0 && first[s] == p) ? 1 : 0;
+    s = a.sslot[l][p];
+    flag = (s >= 0 && a.h[l].first[s] == p) ? 1 : 0;
   }
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned long long bal = __ballot(flag);
-  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
-  if (lane == 0) wave_off[wave] = __popcll(bal);
-  __syncthreads();
-  int off = 0, tot = 0;
-  for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
-    const int c = wave_off[i];
-    if (i < wave) off += c;
-    tot += c;
-  }
+  const int r = block_exclusive_scan(flag, a.block_sums + l * a.sums_stride, lds, wave_off);
   if (flag) {
-    const int r = base + off + in_wave;
-    rank[s] = r;
-    vkeys[r] = srckey[p];
+    a.h[l].rank[s] = r;
+    a.bslot[l][r] = s;
   }
-  if ((int)blockIdx.x == nblocks - 1 && threadIdx.x == 0) *count_out = base + tot;
+  if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) a.counts[8 + l] = r + flag;
 }
 
-// pass C: source element -> voxel row (inverse map for level 0, parent row for levels >= 1).
-__global__ void k_source_to_row(const int *__restrict__ pslot, const int *__restrict__ rank,
-                                const int *__restrict__ n_ptr, int n_fixed, int *__restrict__ inv) {
-  const int n = n_ptr ? *n_ptr : n_fixed;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-    const int s = pslot[p];
-    inv[p] = s >= 0 ? rank[s] : -1;
+// voxel rows, pass A: voxels (popcount) per SCAN_BLOCK blocks.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_block_count(PyramidArgs a, int lv0) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  const int l = lv0 + blockIdx.y;
+  const int n = a.counts[8 + l];
+  if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
+  const int r = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int cnt = r < n ? __popcll(a.h[l].mask[a.bslot[l][r]]) : 0;
+  const int tot = block_reduce_sum(cnt, lds);
+  if (threadIdx.x == 0) a.block_sums[l * a.sums_stride + blockIdx.x] = tot;
+}
+
+// pass B: bbase = exclusive scan of the popcounts; compact per-block arrays; voxel count.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_block_base(PyramidArgs a, int lv0) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int wave_off[SCAN_BLOCK / 64];
+  const int l = lv0 + blockIdx.y;
+  const int n = a.counts[8 + l];
+  const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+  if ((int)blockIdx.x >= nwg) return;
+  const int r = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  unsigned long long m = 0;
+  int s = -1;
+  if (r < n) {
+    s = a.bslot[l][r];
+    m = a.h[l].mask[s];
+  }
+  const int cnt = __popcll(m);
+  const int base = block_exclusive_scan(cnt, a.block_sums + l * a.sums_stride, lds, wave_off);
+  if (r < n) {
+    a.bkey[l][r] = a.h[l].keys[s];
+    a.bmask[l][r] = m;
+    a.bbase[l][r] = base;
+    int4 *ch = reinterpret_cast<int4 *>(a.bchild[l] + (size_t)r * 8);
+    ch[0] = make_int4(-1, -1, -1, -1);
+    ch[1] = make_int4(-1, -1, -1, -1);
+  }
+  if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) a.counts[l] = base + cnt;
+}
+
+// point -> voxel row (inverse map of TensorField.sparse / slice, models.py:25,28); also records the
+// (block, bit) of every level-0 row (all points of a voxel write the same values).
+__global__ void k_points_rows(const int *__restrict__ sslot, const unsigned char *__restrict__ sbit, int n, BHash h,
+                              const int *__restrict__ bbase, int *__restrict__ inv, int *__restrict__ vblock,
+                              unsigned char *__restrict__ vbit) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int s = sslot[p];
+  int row = -1;
+  if (s >= 0) {
+    const int r = h.rank[s];
+    const int bit = sbit[p];
+    row = bbase[r] + __popcll(h.mask[s] & ((1ull << bit) - 1ull));
+    vblock[row] = r;
+    vbit[row] = (unsigned char)bit;
+  }
+  inv[p] = row;
+}
+
+// blockIdx.y = l in 0..3.  (a) parent / child block links between level l and l+1 (one hash probe per
+// block); (b) for l = 0 only, one thread per level-0 block also writes the (block, bit) of the rows it
+// covers at every coarser level (each coarse voxel is covered by at least one level-0 block).
+__global__ void k_link_levels(PyramidArgs a) {
+  const int l = blockIdx.y;
+  const int n = a.counts[8 + l];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const uint64_t key = a.bkey[l][r];
+    const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF),
+                   bz = (uint32_t)((key >> 36) & 0x3FFFF);
+    const uint64_t bt = key & (0x3FFull << 54);
+    const uint64_t pkey = bt | ((uint64_t)(bz >> 1) << 36) | ((uint64_t)(by >> 1) << 18) | (uint64_t)(bx >> 1);
+    const int ps = bhash_find(a.h[l + 1], pkey);
+    const int pr = a.h[l + 1].rank[ps];
+    a.bparent[l][r] = pr;
+    a.bchild[l + 1][(size_t)pr * 8 + ((bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2))] = r;
+    if (l == 0) {
+      const unsigned long long m = a.bmask[0][r];
+#pragma unroll
+      for (int j = 1; j < NLV; ++j) {
+        const int s = a.sslot[j][r];
+        const int br = a.h[j].rank[s];
+        const unsigned long long pmask = a.h[j].mask[s];
+        const int base = a.bbase[j][br];
+        if (j == 1) {
+          const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
+#pragma unroll
+          for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+              for (int i = 0; i < 2; ++i)
+                if (m & (0x0000000000330033ull << (2 * i + 8 * jj + 32 * k))) {
+                  const int bit = (int)((2 * oz + k) * 16 + (2 * oy + jj) * 4 + (2 * ox + i));
+                  const int row = base + __popcll(pmask & ((1ull << bit) - 1ull));
+                  a.vblock[1][row] = br;
+                  a.vbit[1][row] = (unsigned char)bit;
+                }
+        } else {
+          const uint32_t px = (bx >> (j - 2)) & 3, py = (by >> (j - 2)) & 3, pz = (bz >> (j - 2)) & 3;
+          const int bit = (int)((pz << 4) | (py << 2) | px);
+          const int row = base + __popcll(pmask & ((1ull << bit) - 1ull));
+          a.vblock[j][row] = br;
+          a.vbit[j][row] = (unsigned char)bit;
+        }
+      }
+    }
+  }
+}
+
+// adjacency of blocks (blockIdx.y = level): badj[r][a] = rank of the block at offset (dbx,dby,dbz,dt)
+// in {-1,0,1}^4, a = (dbx+1) + 3(dby+1) + 9(dbz+1) + 27(dt+1), or -1.  The only hash probes of the
+// kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
+__global__ void k_block_adj(PyramidArgs a) {
+  const int level = blockIdx.y;
+  const int total = a.counts[8 + level] * 81;  // < 2^31: blocks <= points < 2^30 / 81 is enforced by reserve()
+  const int lim = 1 << (16 - level);  // block coordinates of this level live in [0, lim)
+  const BHash h = a.h[level];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i / 81, ad = i - r * 81;
+    const uint64_t key = a.bkey[level][r];
+    const int bx = (int)(key & 0x3FFFF) + (ad % 3 - 1), by = (int)((key >> 18) & 0x3FFFF) + ((ad / 3) % 3 - 1),
+              bz = (int)((key >> 36) & 0x3FFFF) + ((ad / 9) % 3 - 1), tt = (int)((key >> 54) & 0x1F) + (ad / 27 - 1);
+    int res = -1;
+    if (ad == 40) {
+      res = r;
+    } else if (bx >= 0 && bx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32) {
+      const int s = bhash_find(h, bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bx, (uint32_t)by, (uint32_t)bz));
+      if (s >= 0) res = h.rank[s];
+    }
+    a.badj[level][i] = res;
+  }
+}
+
+// hash slots used by this forward go back to "free" (the tables are never memset per scan).
+__global__ void k_bhash_cleanup(PyramidArgs a) {
+  const int l = blockIdx.y;
+  const int n = a.counts[8 + l];
+  const BHash h = a.h[l];
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+    const int s = a.bslot[l][r];
+    h.keys[s] = KEY_EMPTY;
+    h.mask[s] = 0ull;
+    h.first[s] = 0x7F7F7F7F;
+    h.occ[s >> 5] = 0u;  // every in-use slot clears its whole word: all bits of the word belong to this level
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// kernel maps (output-stationary neighbour tables)
+// kernel maps (output-stationary neighbour tables + per-tile offset masks)
 // ------------------------------------------------------------------------------------------
-enum NbrKind { NBR_3333 = 0, NBR_5551 = 1, NBR_DOWN = 2 };
+enum NbrKind { NBR_3333 = 0, NBR_5551 = 1 };
 
-// nbr[k*ldn + u] = row (in the `in` table) of coordinate out_key[u] + offset_k, or -1  (App. A.6-A.8).
-//   NBR_3333 : k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1), spatial offsets * ts
-//   NBR_5551 : k = (dx+2) + 5(dy+2) + 25(dz+2)
-//   NBR_DOWN : k = dx + 2dy + 4dz, d in {0,1} * ts (ts = stride of the INPUT = finer level)
-template <int KIND>
-__global__ void k_build_nbr(const uint64_t *__restrict__ out_keys, const int *__restrict__ n_out, int ts,
-                            HashTable in, int *__restrict__ nbr, int64_t ldn, uint32_t *__restrict__ tmask) {
+struct LevelView {
+  const int *vblock;
+  const unsigned char *vbit;
+  const uint64_t *bkey;
+  const unsigned long long *bmask;
+  const int *bbase;
+  const int *badj;
+  const int *bparent;
+  const int *bchild;
+};
+
+// bit k of tile (u >> 4): "some row of the 16-row tile has a neighbour through offset k".
+// blockDim.x and the grid stride are multiples of 64, so a 16-lane segment of a wave is one tile.
+__device__ inline void tile_mask_or(uint32_t *tmask, int u, int k, bool present) {
+  const unsigned long long bal = __ballot(present);
+  const int lane = threadIdx.x & 63;
+  if ((lane & 15) == 0 && ((bal >> lane) & 0xFFFFull)) atomicOr(&tmask[(size_t)(u >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+}
+
+// Per-level arguments of the flattened multi-level map kernels: workgroup blockIdx.x belongs to the
+// level l with chunk_off[l] <= blockIdx.x < chunk_off[l+1] and handles rows
+// (blockIdx.x - chunk_off[l]) * 256 ... of that level (grid-stride over chunks[l] workgroups).
+struct MapsArgs {
+  LevelView L[NLV];
+  int *nbr3[NLV];
+  uint32_t *tm3[NLV];
+  int *down[NLV], *up[NLV], *parent_row[NLV];  // index = coarse level (1..4)
+  uint32_t *tmdown[NLV], *tmup[NLV];
+  const int *counts;
+  int chunk_off[NLV + 1];
+  int64_t ldn;
+};
+
+__device__ inline int level_of_chunk(const MapsArgs &a, int first_level, int &local) {
+  int l = first_level;
+  while (l + 1 < NLV && (int)blockIdx.x >= a.chunk_off[l + 1]) ++l;
+  local = (int)blockIdx.x - a.chunk_off[l];
+  return l;
+}
+
+// Rows of the voxels at (position of (r, bit)) + (dx, dy, dz, dt) for dx = -R..R, written to
+// nbr[(k0 + dx + R) * ldn + u]: the dx run touches at most two neighbour blocks, whose adjacency /
+// mask / base are fetched once.
+template <int R>
+__device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int dt, int k0, int *__restrict__ nbr,
+                                  int64_t ldn, uint32_t *__restrict__ tmask) {
+  const int r = L.vblock[u];
+  const int bit = L.vbit[u];
+  const int px = bit & 3, ty = ((bit >> 2) & 3) + dy, tz = (bit >> 4) + dz;
+  const int ad0 = (dt + 1) * 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
+  const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
+  int last_bo = 99, base = 0;
+  unsigned long long mk = 0ull;
+#pragma unroll
+  for (int dx = -R; dx <= R; ++dx) {
+    const int tx = px + dx;
+    const int bo = tx >> 2;
+    if (bo != last_bo) {
+      last_bo = bo;
+      const int nb = L.badj[(size_t)r * 81 + ad0 + bo];
+      mk = nb >= 0 ? L.bmask[nb] : 0ull;
+      base = nb >= 0 ? L.bbase[nb] : 0;
+    }
+    const int nbit = nbit0 | (tx & 3);
+    int row = -1;
+    if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
+    const int k = k0 + dx + R;
+    nbr[(size_t)k * ldn + u] = row;
+    tile_mask_or(tmask, u, k, row >= 0);
+  }
+}
+
+// nbr[k*ldn + u] = row of the voxel at (coordinate of u) + offset_k, or -1   (App. A.6-A.8)
+//   3x3x3x3 (all levels): k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1); blockIdx.y = (dy,dz,dt) combo
+// offsets are in units of the level's stride (the block grid already is).
+__global__ __launch_bounds__(256) void k_build_nbr3(MapsArgs a) {
+  int local;
+  const int l = level_of_chunk(a, 0, local);
+  const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
+  const int n = a.counts[l];
+  const int c = blockIdx.y;  // 0..26
+  const int dy = c % 3 - 1, dz = (c / 3) % 3 - 1, dt = c / 9 - 1;
+  const LevelView L = a.L[l];
+  for (int u = local * 256 + threadIdx.x; u < n; u += nchunks * 256)
+    lookup_run<1>(L, u, dy, dz, dt, 3 * c, a.nbr3[l], a.ldn, a.tm3[l]);
+}
+
+//   5x5x5x1 (level 0): k = (dx+2) + 5(dy+2) + 25(dz+2); blockIdx.y = (dy,dz) combo
+__global__ __launch_bounds__(256) void k_build_nbr5(const int *__restrict__ n_out, LevelView L, int *__restrict__ nbr,
+                                                     int64_t ldn, uint32_t *__restrict__ tmask) {
   const int n = *n_out;
-  const int k = blockIdx.y;
-  int dx, dy, dz, dt = 0;
-  if (KIND == NBR_3333) {
-    dx = (k % 3 - 1) * ts;
-    dy = ((k / 3) % 3 - 1) * ts;
-    dz = ((k / 9) % 3 - 1) * ts;
-    dt = k / 27 - 1;
-  } else if (KIND == NBR_5551) {
-    dx = (k % 5 - 2) * ts;
-    dy = ((k / 5) % 5 - 2) * ts;
-    dz = (k / 25 - 2) * ts;
-  } else {
-    dx = (k & 1) * ts;
-    dy = ((k >> 1) & 1) * ts;
-    dz = ((k >> 2) & 1) * ts;
-  }
-  // blockDim.x and the grid stride are multiples of 64, so lane l always handles a row = l (mod 64):
-  // a 16-lane segment of the wave is one 16-row tile of the output-stationary convolution.
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    int b, x, y, z, t;
-    key_unpack(out_keys[u], b, x, y, z, t);
-    x += dx;
-    y += dy;
-    z += dz;
-    t += dt;
-    int r = -1;
-    if (key_in_range(b, x, y, z, t)) r = hash_lookup(in, key_pack(b, x, y, z, t));
-    nbr[(size_t)k * ldn + u] = r;
-    // tile mask: bit k of tile (u >> 4) = "some row of the tile has a neighbour through offset k"
-    const unsigned long long bal = __ballot(r >= 0);
-    const int lane = threadIdx.x & 63;
-    if ((lane & 15) == 0 && ((bal >> lane) & 0xFFFFull)) atomicOr(&tmask[(size_t)(u >> 4) * 4 + (k >> 5)], 1u << (k & 31));
-  }
+  const int c = blockIdx.y;  // 0..24
+  const int dy = c % 5 - 2, dz = c / 5 - 2;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
+    lookup_run<2>(L, u, dy, dz, 0, 5 * c, nbr, ldn, tmask);
 }
 
-// transposed conv map (App. A.10): fine voxel v receives exactly one term, from its parent, through
-// offset k = octant of v inside the parent:  up[k*ldn + v] = (k == oct(v)) ? parent[v] : -1.
-__global__ void k_build_up(const uint64_t *__restrict__ fine_keys, const int *__restrict__ n_fine, int ts,
-                           const int *__restrict__ parent, int *__restrict__ up, int64_t ldn,
-                           uint32_t *__restrict__ tmask) {
-  const int n = *n_fine;
-  int sh = 0;
-  while ((1 << sh) < ts) ++sh;
-  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x) {
-    const uint64_t key = fine_keys[v];
-    const int oct = (int)((key >> sh) & 1) | ((int)((key >> (18 + sh)) & 1) << 1) | ((int)((key >> (36 + sh)) & 1) << 2);
-    const int par = parent[v];
-    const int lane = threadIdx.x & 63;
+// Stride maps of all four level pairs in one launch.  chunk_off here is indexed by the FINE level
+// f = 0..3 (coarse level c = f + 1); each workgroup does both directions for its rows:
+//  down (App. A.9):  out = coarse voxel u, children at u + {0,1}^3 (fine units), k = dx + 2dy + 4dz
+//  up   (App. A.10): fine voxel v receives exactly one term, from its parent, through offset
+//                    k = position of v inside the parent: up[k*ldn + v] = (k == oct(v)) ? parent : -1
+__global__ __launch_bounds__(256) void k_build_stride_maps(MapsArgs a) {
+  int local;
+  const int f = level_of_chunk(a, 0, local);
+  if (f >= NLV - 1) return;
+  const int c = f + 1;
+  const int nchunks = a.chunk_off[f + 1] - a.chunk_off[f];
+  const LevelView F = a.L[f], C = a.L[c];
+  const int nf = a.counts[f], nc = a.counts[c];
+  // ---- up map + parent rows (rows = fine voxels)
+  for (int v = local * 256 + threadIdx.x; v < nf; v += nchunks * 256) {
+    const int r = F.vblock[v];
+    const int bit = F.vbit[v];
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const uint64_t key = F.bkey[r];
+    const int ox = (int)(key & 1), oy = (int)((key >> 18) & 1), oz = (int)((key >> 36) & 1);
+    const int pr = F.bparent[r];
+    const int pbit = ((oz * 2 + (pz >> 1)) << 4) | ((oy * 2 + (py >> 1)) << 2) | (ox * 2 + (px >> 1));
+    const int par = C.bbase[pr] + __popcll(C.bmask[pr] & ((1ull << pbit) - 1ull));
+    const int oct = (px & 1) | ((py & 1) << 1) | ((pz & 1) << 2);
+    a.parent_row[c][v] = par;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      up[(size_t)k * ldn + v] = (k == oct) ? par : -1;
-      const unsigned long long bal = __ballot(k == oct && par >= 0);
-      if ((lane & 15) == 0 && ((bal >> lane) & 0xFFFFull)) atomicOr(&tmask[(size_t)(v >> 4) * 4], 1u << k);
+      a.up[c][(size_t)k * a.ldn + v] = (k == oct) ? par : -1;
+      tile_mask_or(a.tmup[c], v, k, k == oct);
+    }
+  }
+  // ---- down map (rows = coarse voxels)
+  for (int u = local * 256 + threadIdx.x; u < nc; u += nchunks * 256) {
+    const int r = C.vblock[u];
+    const int bit = C.vbit[u];
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const int cb = C.bchild[(size_t)r * 8 + ((px >> 1) | ((py >> 1) << 1) | ((pz >> 1) << 2))];
+    const unsigned long long mk = cb >= 0 ? F.bmask[cb] : 0ull;
+    const int base = cb >= 0 ? F.bbase[cb] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+      const int cbit = ((((pz & 1) << 1) + dz) << 4) | ((((py & 1) << 1) + dy) << 2) | (((px & 1) << 1) + dx);
+      int row = -1;
+      if ((mk >> cbit) & 1ull) row = base + __popcll(mk & ((1ull << cbit) - 1ull));
+      a.down[c][(size_t)k * a.ldn + u] = row;
+      tile_mask_or(a.tmdown[c], u, k, row >= 0);
     }
   }
 }
@@ -675,17 +1019,19 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_keep_write(const int *__restrict
 // ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
-__global__ void k_keys_to_coords(const uint64_t *__restrict__ keys, int n, int32_t *__restrict__ out) {
+__global__ void k_rows_to_coords(const int *__restrict__ vblock, const unsigned char *__restrict__ vbit,
+                                 const uint64_t *__restrict__ bkey, int level, int n, int32_t *__restrict__ out) {
   const int v = blockIdx.x * blockDim.x + threadIdx.x;
   if (v >= n) return;
-  int b, x, y, z, t;
-  key_unpack(keys[v], b, x, y, z, t);
+  const uint64_t key = bkey[vblock[v]];
+  const int bit = vbit[v];
+  const int bx = (int)(key & 0x3FFFF), by = (int)((key >> 18) & 0x3FFFF), bz = (int)((key >> 36) & 0x3FFFF);
   int32_t *o = out + (size_t)v * 5;
-  o[0] = b;
-  o[1] = x;
-  o[2] = y;
-  o[3] = z;
-  o[4] = t;
+  o[0] = (int)(key >> 59);
+  o[1] = (((bx << 2) | (bit & 3)) << level) - XBIAS;
+  o[2] = (((by << 2) | ((bit >> 2) & 3)) << level) - XBIAS;
+  o[3] = (((bz << 2) | (bit >> 4)) << level) - XBIAS;
+  o[4] = (int)((key >> 54) & 0x1F) - TBIAS;
 }
 __global__ void k_i32_to_i64(const int *__restrict__ in, int n, int64_t *__restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -820,15 +1166,34 @@ inline int64_t next_pow2(int64_t v) {
 }
 
 struct Level {
-  HashTable h{};
-  uint64_t *vkeys = nullptr;   // [cap] voxel keys in row order
-  uint64_t *srckey = nullptr;  // [cap] key of each source element
-  int *pslot = nullptr;        // [cap] slot of each source element
-  int *inv = nullptr;          // [cap] source element -> row (level 0: point->voxel, else parent row)
+  BHash h{};
+  // per block, rank order [cap]
+  int *bslot = nullptr;
+  uint64_t *bkey = nullptr;
+  unsigned long long *bmask = nullptr;
+  int *bbase = nullptr;
+  int *bparent = nullptr;  // rank of the parent block (level + 1)
+  int *bchild = nullptr;   // [cap][8] rank of the child block (level - 1) per octant
+  int *badj = nullptr;     // [cap][81]
+  // per voxel row [cap]
+  int *vblock = nullptr;
+  unsigned char *vbit = nullptr;
+  // per source [cap]: hash slot of the block the source fell into (level 0: points, else level-1 blocks)
+  int *sslot = nullptr;
+  unsigned char *sbit = nullptr;  // level 0 only
+  int *inv = nullptr;             // level 0: point -> row; levels 1..4: row of level-1 voxel -> parent row
+  // kernel maps
   int *nbr3 = nullptr;         // [81][cap]
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
   int *up = nullptr;           // [8][cap]  (levels 1..4) indexed by level-1 voxel
   uint32_t *tm3 = nullptr, *tmdown = nullptr, *tmup = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
+  LevelView view() const { return LevelView{vblock, vbit, bkey, bmask, bbase, badj, bparent, bchild}; }
+};
+
+struct SubmapScratch {  // variant-B submap: voxel-level hash with first-occurrence order
+  HashTable h{};
+  uint64_t *srckey = nullptr;
+  int *pslot = nullptr;
 };
 
 struct Feat {
@@ -847,8 +1212,11 @@ struct sps_ctx {
   bool have_weights = false;
   std::vector<void *> allocs;
   Level lv[SPS_NUM_LEVELS];
+  SubmapScratch sub;
+  bool tables_dirty = true;  // block hashes need a full reset (first use / aborted forward)
+  void *hash_keys_all = nullptr, *hash_mask_all = nullptr, *hash_first_all = nullptr, *hash_occ_all = nullptr;
   int *nbr5 = nullptr;       // [125][cap]
-  int *counts = nullptr;     // device: [0..4] voxels per level, [5] submap rows, [6] scan voxels, [7] spare
+  int *counts = nullptr;     // device: [0..4] voxels per level, [5] submap rows, [6] scan voxels, [8..12] blocks per level
   int *err = nullptr;        // device error flag
   int *block_sums = nullptr;
   int *keep = nullptr;
@@ -857,8 +1225,9 @@ struct sps_ctx {
   float *blob = nullptr;     // weights
   float *ss = nullptr;       // folded scale/shift
   float *wu = nullptr;       // unit-major permuted conv kernels (k_conv B operand)
-  uint32_t *tmask_all = nullptr, *tm5 = nullptr;  // all tile masks (one memset per forward)
-  size_t tmask_bytes = 0;
+  uint32_t *tm5 = nullptr;
+  void *zero_region = nullptr;  // [counts (16 ints) | all tile masks]: one fill per forward
+  size_t zero_bytes = 0;
   float *slab = nullptr;     // split-K partial sums
   int64_t slab_stride = 0;
   // feature buffers
@@ -910,28 +1279,63 @@ int reserve(sps_ctx *c, int64_t n) {
   free_arena(c);
   const int64_t cap = ((n + 1023) / 1024) * 1024;
   const int64_t hcap = next_pow2(2 * cap);
-  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
-    Level &L = c->lv[l];
-    ALLOC(L.h.keys, uint64_t, hcap);
-    ALLOC(L.h.first, int, hcap);
-    ALLOC(L.h.rank, int, hcap);
-    L.h.mask = (uint32_t)(hcap - 1);
-    ALLOC(L.vkeys, uint64_t, cap);
-    ALLOC(L.srckey, uint64_t, cap);
-    ALLOC(L.pslot, int, cap);
-    ALLOC(L.inv, int, cap);
-    ALLOC(L.nbr3, int, 81 * cap);
-    if (l > 0) {
-      ALLOC(L.down, int, 8 * cap);
-      ALLOC(L.up, int, 8 * cap);
+  {
+    // block hashes of all levels live in three allocations (one reset each when dirty)
+    uint64_t *keys;
+    unsigned long long *mask;
+    int *first;
+    ALLOC(keys, uint64_t, hcap * SPS_NUM_LEVELS);
+    ALLOC(mask, unsigned long long, hcap * SPS_NUM_LEVELS);
+    ALLOC(first, int, hcap * SPS_NUM_LEVELS);
+    uint32_t *occ;
+    ALLOC(occ, uint32_t, (hcap / 32) * SPS_NUM_LEVELS);
+    c->hash_occ_all = occ;
+    c->hash_keys_all = keys;
+    c->hash_mask_all = mask;
+    c->hash_first_all = first;
+    for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+      Level &L = c->lv[l];
+      L.h.keys = keys + (size_t)l * hcap;
+      L.h.mask = mask + (size_t)l * hcap;
+      L.h.first = first + (size_t)l * hcap;
+      ALLOC(L.h.rank, int, hcap);
+      L.h.occ = occ + (size_t)l * (hcap / 32);
+      L.h.hmask = (uint32_t)(hcap - 1);
+      ALLOC(L.bslot, int, cap);
+      ALLOC(L.bkey, uint64_t, cap);
+      ALLOC(L.bmask, unsigned long long, cap);
+      ALLOC(L.bbase, int, cap);
+      ALLOC(L.bparent, int, cap);
+      ALLOC(L.bchild, int, 8 * cap);
+      ALLOC(L.badj, int, 81 * cap);
+      ALLOC(L.vblock, int, cap);
+      ALLOC(L.vbit, unsigned char, cap);
+      ALLOC(L.sslot, int, cap);
+      if (l == 0) ALLOC(L.sbit, unsigned char, cap);
+      ALLOC(L.inv, int, cap);
+      ALLOC(L.nbr3, int, 81 * cap);
+      if (l > 0) {
+        ALLOC(L.down, int, 8 * cap);
+        ALLOC(L.up, int, 8 * cap);
+      }
     }
+    c->tables_dirty = true;
+    ALLOC(c->sub.h.keys, uint64_t, hcap);
+    ALLOC(c->sub.h.first, int, hcap);
+    ALLOC(c->sub.h.rank, int, hcap);
+    c->sub.h.mask = (uint32_t)(hcap - 1);
+    ALLOC(c->sub.srckey, uint64_t, cap);
+    ALLOC(c->sub.pslot, int, cap);
   }
   ALLOC(c->nbr5, int, 125 * cap);
   {
     const size_t tm_words = (size_t)(cap / 16) * 4;  // cap is a multiple of 1024
-    ALLOC(c->tmask_all, uint32_t, tm_words * 14);
-    c->tmask_bytes = tm_words * 14 * sizeof(uint32_t);
-    uint32_t *p = c->tmask_all;
+    uint32_t *zr;
+    ALLOC(zr, uint32_t, 16 + tm_words * 14);
+    c->zero_region = zr;
+    c->zero_bytes = (16 + tm_words * 14) * sizeof(uint32_t);
+    c->counts = reinterpret_cast<int *>(zr);
+    uint32_t *p = zr + 16;
     c->tm5 = p;
     p += tm_words;
     for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
@@ -947,7 +1351,7 @@ int reserve(sps_ctx *c, int64_t n) {
   }
   c->slab_stride = cap * 64;
   ALLOC(c->slab, float, (size_t)MAX_SPLIT * c->slab_stride);
-  ALLOC(c->block_sums, int, cap / SCAN_BLOCK + 8);
+  ALLOC(c->block_sums, int, (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
   ALLOC(c->keep, int, cap);
   ALLOC(c->cat8, float, 16 * cap);
   ALLOC(c->b8t, float, 8 * cap);
@@ -981,7 +1385,7 @@ int reserve(sps_ctx *c, int64_t n) {
   c->cap = cap;
   c->hcap = hcap;
   c->last_n = 0;
-  HIP_TRY(hipMemset(c->counts, 0, 8 * sizeof(int)));
+  HIP_TRY(hipMemset(c->zero_region, 0, c->zero_bytes));
   return SPS_OK;
 }
 
@@ -992,18 +1396,26 @@ inline int grid_for(int64_t n, int block, int maxb = 2048) {
   return (int)g;
 }
 
-// first-occurrence compaction of the source elements of `L` (already inserted)
-int rank_level(sps_ctx *c, Level &L, const int *n_ptr, int n_fixed, int64_t n_bound, int *count_out,
-               hipStream_t st) {
-  const int nb = (int)((n_bound + SCAN_BLOCK - 1) / SCAN_BLOCK);
-  const int nbl = nb < 1 ? 1 : nb;
-  hipLaunchKernelGGL(k_first_count, dim3(nbl), dim3(SCAN_BLOCK), 0, st, L.pslot, L.h.first, n_ptr, n_fixed,
-                     c->block_sums);
-  hipLaunchKernelGGL(k_first_rank, dim3(nbl), dim3(SCAN_BLOCK), 0, st, L.pslot, L.h.first, L.srckey, n_ptr, n_fixed,
-                     c->block_sums, L.h.rank, L.vkeys, count_out);
-  hipLaunchKernelGGL(k_source_to_row, dim3(grid_for(n_bound, 256)), dim3(256), 0, st, L.pslot, L.h.rank, n_ptr,
-                     n_fixed, L.inv);
-  return SPS_OK;
+PyramidArgs pyramid_args(sps_ctx *c) {
+  PyramidArgs a{};
+  for (int l = 0; l < NLV; ++l) {
+    const Level &L = c->lv[l];
+    a.h[l] = L.h;
+    a.sslot[l] = L.sslot;
+    a.bslot[l] = L.bslot;
+    a.bkey[l] = L.bkey;
+    a.bmask[l] = L.bmask;
+    a.bbase[l] = L.bbase;
+    a.bparent[l] = L.bparent;
+    a.bchild[l] = L.bchild;
+    a.badj[l] = L.badj;
+    a.vblock[l] = L.vblock;
+    a.vbit[l] = L.vbit;
+  }
+  a.counts = c->counts;
+  a.block_sums = c->block_sums;
+  a.sums_stride = (int)(c->cap / SCAN_BLOCK + 8);
+  return a;
 }
 
 struct Map {
@@ -1153,14 +1565,12 @@ int sps_ctx_create(int device, sps_ctx **out) {
   sps_ctx *c = new sps_ctx();
   c->device = device;
   const NetSpec &s = spec();
-  HIP_TRY(hipMalloc((void **)&c->counts, 8 * sizeof(int)));
   HIP_TRY(hipMalloc((void **)&c->err, sizeof(int)));
   HIP_TRY(hipMalloc((void **)&c->macc, 32 * 8 * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&c->pairs, 128 * sizeof(unsigned long long)));
   HIP_TRY(hipMalloc((void **)&c->blob, s.numel * sizeof(float)));
   HIP_TRY(hipMalloc((void **)&c->ss, s.ss_numel * sizeof(float)));
   HIP_TRY(hipMalloc((void **)&c->wu, s.wu_numel * sizeof(float)));
-  HIP_TRY(hipMemset(c->counts, 0, 8 * sizeof(int)));
   HIP_TRY(hipMemset(c->err, 0, sizeof(int)));
   *out = c;
   return SPS_OK;
@@ -1171,7 +1581,6 @@ int sps_ctx_destroy(sps_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   free_arena(c);
-  (void)hipFree(c->counts);
   (void)hipFree(c->err);
   (void)hipFree(c->macc);
   (void)hipFree(c->pairs);
@@ -1185,7 +1594,7 @@ int sps_ctx_destroy(sps_ctx *c) {
 
 int sps_reserve(sps_ctx *c, int64_t max_points) {
   if (!c || max_points < 0) return fail(SPS_ERR_INVALID, "bad arguments");
-  if (max_points >= (1ll << 30)) return fail(SPS_ERR_INVALID, "max_points too large");
+  if (max_points > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "max_points too large (limit %d)", SPS_MAX_POINTS);
   return reserve(c, max_points < 1024 ? 1024 : max_points);
 }
 
@@ -1245,7 +1654,7 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   if (!c->have_weights) return fail(SPS_ERR_NOWEIGHTS, "sps_weights_load has not been called");
   if (n < 0 || ld < 5 || (n > 0 && (!coords || !scores))) return fail(SPS_ERR_INVALID, "bad arguments");
   if (!(vs > 0.f)) return fail(SPS_ERR_INVALID, "voxel_size must be > 0");
-  if (n >= (1ll << 30)) return fail(SPS_ERR_INVALID, "too many points");
+  if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points (limit %d)", SPS_MAX_POINTS);
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   if (n > c->cap) {
@@ -1256,48 +1665,71 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   const int64_t cap = c->cap;
   c->prof_n = 0;
   prof_mark(c, "begin", st);
-  // ---- reset hash tables
-  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
-    HIP_TRY(hipMemsetAsync(c->lv[l].h.keys, 0xFF, (size_t)c->hcap * sizeof(uint64_t), st));
-    HIP_TRY(hipMemsetAsync(c->lv[l].h.first, 0x7F, (size_t)c->hcap * sizeof(int), st));
+  // ---- reset: the block hashes are cleaned by the previous forward; full reset only when dirty
+  if (c->tables_dirty) {
+    HIP_TRY(hipMemsetAsync(c->hash_keys_all, 0xFF, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(uint64_t), st));
+    HIP_TRY(hipMemsetAsync(c->hash_mask_all, 0, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->hash_first_all, 0x7F, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->hash_occ_all, 0, (size_t)(c->hcap / 32) * SPS_NUM_LEVELS * sizeof(uint32_t), st));
   }
-  HIP_TRY(hipMemsetAsync(c->counts, 0, 5 * sizeof(int), st));
-  HIP_TRY(hipMemsetAsync(c->tmask_all, 0, c->tmask_bytes, st));
-  if (n == 0) return SPS_OK;
+  c->tables_dirty = true;
+  HIP_TRY(hipMemsetAsync(c->zero_region, 0, c->zero_bytes, st));  // counts + every tile mask, one fill
+  if (n == 0) {
+    c->tables_dirty = false;
+    return SPS_OK;
+  }
   prof_mark(c, "reset", st);
 
-  // ---- level 0: points -> voxels
+  // ---- level 0: points -> blocks -> voxel rows
   Level &L0 = c->lv[0];
-  hipLaunchKernelGGL(k_points_insert, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, coords, ld, (int)n, vs,
-                     L0.h, L0.srckey, L0.pslot, c->err);
-  rank_level(c, L0, nullptr, (int)n, n, c->counts + 0, st);
+  const PyramidArgs pa = pyramid_args(c);
+  const unsigned gp = (unsigned)((n + 255) / 256);
+  const unsigned gs0 = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  const unsigned gsb = (unsigned)(cap / SCAN_BLOCK);  // bound for scans over blocks
+  hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, L0.h, L0.sslot, L0.sbit,
+                     c->err);
+  hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
+  hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
+  hipLaunchKernelGGL(k_block_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0);
+  hipLaunchKernelGGL(k_block_base, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0);
+  hipLaunchKernelGGL(k_points_rows, dim3(gp), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
+                     L0.vblock, L0.vbit);
   prof_mark(c, "voxelize", st);
-  // ---- levels 1..4: stride-2 pyramid
-  for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
-    Level &F = c->lv[l - 1], &L = c->lv[l];
-    const int ts = 1 << (l - 1);
-    hipLaunchKernelGGL(k_parent_insert, dim3(grid_for(cap, 256)), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts,
-                       L.h, L.srckey, L.pslot);
-    rank_level(c, L, c->counts + (l - 1), 0, cap, c->counts + l, st);
-  }
+  // ---- levels 1..4: every coarser level straight from the level-0 blocks, batched over levels
+  const int gb = grid_for(cap >> 2, 256, 256);
+  const unsigned gsl = gsb > 16 ? gsb / 4 : gsb;  // level-0 blocks are far fewer than points
+  hipLaunchKernelGGL(k_blocks_to_ancestors, dim3(gb, 4), dim3(256), 0, st, pa);
+  hipLaunchKernelGGL(k_first_count, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
+  hipLaunchKernelGGL(k_first_rank, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
+  hipLaunchKernelGGL(k_block_count, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1);
+  hipLaunchKernelGGL(k_block_base, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1);
+  hipLaunchKernelGGL(k_link_levels, dim3(gb, 4), dim3(256), 0, st, pa);
+  (void)gsl;
   prof_mark(c, "pyramid", st);
   // ---- kernel maps
+  hipLaunchKernelGGL(k_block_adj, dim3(grid_for(cap >> 1, 256, 1024), NLV), dim3(256), 0, st, pa);
+  MapsArgs ma{};
+  int off = 0;
+  for (int l = 0; l < NLV; ++l) {
+    const Level &L = c->lv[l];
+    ma.L[l] = L.view();
+    ma.nbr3[l] = L.nbr3;
+    ma.tm3[l] = L.tm3;
+    ma.down[l] = L.down;
+    ma.up[l] = L.up;
+    ma.parent_row[l] = L.inv;
+    ma.tmdown[l] = L.tmdown;
+    ma.tmup[l] = L.tmup;
+    ma.chunk_off[l] = off;
+    off += grid_for(cap >> l, 256, 1024);
+  }
+  ma.chunk_off[NLV] = off;
+  ma.counts = c->counts;
+  ma.ldn = cap;
   const int gx = grid_for(cap, 256, 1024);
-  hipLaunchKernelGGL(k_build_nbr<NBR_5551>, dim3(gx, 125), dim3(256), 0, st, L0.vkeys, c->counts + 0, 1, L0.h,
-                     c->nbr5, cap, c->tm5);
-  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
-    Level &L = c->lv[l];
-    hipLaunchKernelGGL(k_build_nbr<NBR_3333>, dim3(gx, 81), dim3(256), 0, st, L.vkeys, c->counts + l, 1 << l, L.h,
-                       L.nbr3, cap, L.tm3);
-  }
-  for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
-    Level &F = c->lv[l - 1], &L = c->lv[l];
-    const int ts = 1 << (l - 1);
-    hipLaunchKernelGGL(k_build_nbr<NBR_DOWN>, dim3(gx, 8), dim3(256), 0, st, L.vkeys, c->counts + l, ts, F.h, L.down,
-                       cap, L.tmdown);
-    hipLaunchKernelGGL(k_build_up, dim3(gx), dim3(256), 0, st, F.vkeys, c->counts + (l - 1), ts, L.inv, L.up, cap,
-                       L.tmup);
-  }
+  hipLaunchKernelGGL(k_build_nbr5, dim3(gx, 25), dim3(256), 0, st, c->counts + 0, L0.view(), c->nbr5, cap, c->tm5);
+  hipLaunchKernelGGL(k_build_nbr3, dim3(off, 27), dim3(256), 0, st, ma);
+  hipLaunchKernelGGL(k_build_stride_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma);
   prof_mark(c, "maps", st);
   // ---- network (minkunet.py:161-219)
   Level *lv = c->lv;
@@ -1344,7 +1776,10 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->logits, L0.inv, (int)n,
                      scores);
   prof_mark(c, "slice_sigmoid", st);
+  hipLaunchKernelGGL(k_bhash_cleanup, dim3(grid_for(cap >> 2, 256, 256), NLV), dim3(256), 0, st, pa);
+  prof_mark(c, "cleanup", st);
   HIP_TRY(hipGetLastError());
+  c->tables_dirty = false;
   return SPS_OK;
 }
 
@@ -1444,7 +1879,7 @@ static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_
   if (!c->map.keys) return fail(SPS_ERR_INVALID, "sps_map_upload has not been called");
   if (n < 0 || ld < 3 || (n > 0 && (!src || !out_xyz))) return fail(SPS_ERR_INVALID, "bad arguments");
   if (!(ds > 0.f)) return fail(SPS_ERR_INVALID, "ds must be > 0");
-  if (n >= (1ll << 30)) return fail(SPS_ERR_INVALID, "too many points");
+  if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points (limit %d)", SPS_MAX_POINTS);
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   *n_sub = 0;
@@ -1454,7 +1889,7 @@ static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_
     int rc = reserve(c, n);
     if (rc != SPS_OK) return rc;
   }
-  Level &L = c->lv[0];  // borrow the level-0 scratch (a forward re-initialises it)
+  SubmapScratch &L = c->sub;
   HIP_TRY(hipMemsetAsync(L.h.keys, 0xFF, (size_t)c->hcap * sizeof(uint64_t), st));
   HIP_TRY(hipMemsetAsync(L.h.first, 0x7F, (size_t)c->hcap * sizeof(int), st));
   HIP_TRY(hipMemsetAsync(c->counts + 5, 0, 2 * sizeof(int), st));
@@ -1476,7 +1911,6 @@ static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_
   HIP_TRY(hipStreamSynchronize(st));
   *n_sub = res[0];
   *n_scan_vox = res[1];
-  c->last_n = 0;
   return SPS_OK;
 }
 
@@ -1516,8 +1950,8 @@ int sps_level_counts(sps_ctx *c, int64_t out[SPS_NUM_LEVELS]) {
   if (!c || !out) return fail(SPS_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
-  int h[SPS_NUM_LEVELS];
-  HIP_TRY(hipMemcpy(h, c->counts, sizeof h, hipMemcpyDeviceToHost));
+  int h[SPS_NUM_LEVELS] = {0, 0, 0, 0, 0};
+  if (c->cap > 0 && c->last_n > 0) HIP_TRY(hipMemcpy(h, c->counts, sizeof h, hipMemcpyDeviceToHost));
   for (int l = 0; l < SPS_NUM_LEVELS; ++l) out[l] = h[l];
   return SPS_OK;
 }
@@ -1529,7 +1963,8 @@ int sps_get_voxels(sps_ctx *c, int level, int32_t *coords_dev) {
   if (rc != SPS_OK) return rc;
   const int n = (int)cnt[level];
   if (n > 0)
-    hipLaunchKernelGGL(k_keys_to_coords, dim3((n + 255) / 256), dim3(256), 0, 0, c->lv[level].vkeys, n, coords_dev);
+    hipLaunchKernelGGL(k_rows_to_coords, dim3((n + 255) / 256), dim3(256), 0, 0, c->lv[level].vblock,
+                       c->lv[level].vbit, c->lv[level].bkey, level, n, coords_dev);
   HIP_TRY(hipDeviceSynchronize());
   return SPS_OK;
 }

@@ -55,35 +55,54 @@ def get_feature(name):
     return out.cpu().numpy()
 
 
+def match_rows(got: np.ndarray, want: np.ndarray) -> np.ndarray:
+    """perm with got[i] == want[perm[i]]; asserts that the two coordinate sets are identical.
+    (The HIP path orders voxel rows block by block, the oracle by first occurrence: row order is
+    free, App. A.3 -- only sets, inverse maps and per-row values are compared.)"""
+    assert got.shape == want.shape
+    if len(got) == 0:
+        return np.zeros(0, np.int64)
+    og = np.lexsort(got.T[::-1])
+    ow = np.lexsort(want.T[::-1])
+    np.testing.assert_array_equal(got[og], want[ow])
+    assert len(np.unique(got, axis=0)) == len(got), "duplicate voxel rows"
+    perm = np.empty(len(got), np.int64)
+    perm[og] = ow
+    return perm
+
+
 def check_full(net, params, batch, tol=2e-4):
     dev, scores = run(net, batch)
     ref, info = O.sps_forward(params, batch[:, :5], VS, keep=True)
     counts = ctx().level_counts()
     cm = info["cm"]
-    # --- integer structure: exact, including row order (both sides use first-occurrence order)
+    # --- integer structure: exact (as sets; rows matched by coordinate)
+    perm = []
     for l in range(5):
         ts = 1 << l
         assert counts[l] == len(cm.coords[ts]), f"level {l}"
-        np.testing.assert_array_equal(get_voxels(l, counts[l]), cm.coords[ts])
+        perm.append(match_rows(get_voxels(l, counts[l]), cm.coords[ts]))
     from sps_amd import _native
     inv = torch.empty(len(batch), dtype=torch.int64, device="cuda")
     _native.check(_native.lib.sps_get_inverse(ctx().handle, inv.data_ptr()))
-    np.testing.assert_array_equal(inv.cpu().numpy(), info["inverse"])
+    np.testing.assert_array_equal(perm[0][inv.cpu().numpy()], info["inverse"])
     for l in range(4):
         par = torch.empty(counts[l], dtype=torch.int32, device="cuda")
         _native.check(_native.lib.sps_get_parent(ctx().handle, l, par.data_ptr()))
-        np.testing.assert_array_equal(par.cpu().numpy(), cm.parent[1 << l])
+        np.testing.assert_array_equal(perm[l + 1][par.cpu().numpy()], cm.parent[1 << l][perm[l]])
     for l in range(5):
         want = [len(i) for i, _ in cm.k3(1 << l)]
         assert ctx().map_pairs(l) == want, f"3^4 map level {l}"
     assert ctx().map_pairs(5) == [len(i) for i, _ in cm.k5()]
     # --- features
+    tap_level = {"out_p1": 0, "block1": 1, "block2": 2, "block3": 3, "block4": 4, "block5": 3, "block6": 2,
+                 "block7": 1, "block8": 0}
     for name, want in info["inter"].items():
         got = get_feature(name)
-        np.testing.assert_allclose(got, want, rtol=tol, atol=tol, err_msg=name)
+        np.testing.assert_allclose(got, want[perm[tap_level[name]]], rtol=tol, atol=tol, err_msg=name)
     logits = torch.empty(counts[0], dtype=torch.float32, device="cuda")
     _native.check(_native.lib.sps_get_logits(ctx().handle, logits.data_ptr()))
-    np.testing.assert_allclose(logits.cpu().numpy(), info["logits"], rtol=0, atol=1e-3)
+    np.testing.assert_allclose(logits.cpu().numpy(), info["logits"][perm[0]], rtol=0, atol=1e-3)
     s = scores.cpu().numpy()
     np.testing.assert_allclose(s, ref, rtol=0, atol=1e-4)
     # --- labels: identical outside a tiny band around the threshold
@@ -209,7 +228,7 @@ def test_quantisation_probe_matches_f32_division():
     counts = ctx().level_counts()
     vox = get_voxels(0, counts[0])
     want, inv = O.unique_first(O.quantize(pts, VS))
-    np.testing.assert_array_equal(vox, want)
+    match_rows(vox, want)
 
 
 def test_prune_matches_oracle():
