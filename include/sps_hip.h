@@ -143,6 +143,9 @@ int sps_get_parent(sps_ctx *ctx, int level, int32_t *parent_dev);
 /* Kernel-map pair counts: which = 0..4 -> 3x3x3x3 map at level which; 5 -> 5x5x5x1 map at
  * level 0.  pairs_host[k] = number of (in,out) pairs of offset k (81 or 125 entries). */
 int sps_get_map_pairs(sps_ctx *ctx, int which, int64_t *pairs_host);
+/* Present-offset masks of the 16-row output tiles of a kernel map (which as above): uint32
+ * [n_tiles][4]; bit k set = some row of the tile has a neighbour through offset k. */
+int sps_get_tile_masks(sps_ctx *ctx, int which, uint32_t *masks_dev, int64_t *n_tiles);
 /* Per-voxel logits of the last forward, float32 [V_0]. */
 int sps_get_logits(sps_ctx *ctx, float *logits_dev);
 /* Named intermediate feature maps: "out_p1","block1".."block8"; copies [V,C] row-major

@@ -709,9 +709,16 @@ struct ConvArgs {
 //   B fragment is one coalesced 16-byte load per lane (256 B per lane group).
 //   S > 1: the unit list is cut into S contiguous chunks (blockIdx.z), partial sums go to a slab and
 //   k_reduce_epilogue adds them in fixed order (bit-reproducible, no atomics).
-template <int NTW, bool CIN1>
-__global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
+//   Latency structure: the neighbour rows of up to KCHUNK present offsets x 16 rows are first staged
+//   into LDS by all 64 lanes (independent, coalesced loads); the unit loop then issues the gathers
+//   and weight loads of G groups together before their 4*G*NTW MFMAs, so a wave has G (not 1)
+//   dependent-load round trips in flight.
+constexpr int KCHUNK = 32;
+
+template <int NTW, bool CIN1, int G, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   __shared__ unsigned char klist[4][128];
+  __shared__ int idx_s[4][KCHUNK * 16];
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -719,10 +726,10 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
   const int nt0 = blockIdx.y * NTW;
   const int split = blockIdx.z;
   unsigned char *kl = klist[wave];
+  int *ix = idx_s[wave];
+  const int upk = CIN1 ? 1 : a.upk;
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
     const int row0 = tile * 16;
-    const int row = row0 + r;
-    const bool rvalid = row < count;
     // ---- prologue: compact list of present offsets (wave-synchronous LDS)
     int nk = 1;
     __builtin_amdgcn_wave_barrier();
@@ -740,7 +747,7 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
       kl[0] = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    const int U = CIN1 ? nk : nk * a.upk;
+    const int U = nk * upk;
     int per = (U + a.S - 1) / a.S;
     per = (per + 3) & ~3;
     const int j0 = split * per;
@@ -750,36 +757,62 @@ __global__ __launch_bounds__(256) void k_conv(ConvArgs a) {
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-    for (int jb = j0; jb < j1; jb += 4) {
-      const int j = jb + q;
-      const bool valid = j < j1;
-      if (CIN1) {
-        const int k = valid ? (int)kl[j] : 0;
-        int idx = -1;
-        if (valid && rvalid) idx = a.nbr[(size_t)k * a.ldn + row];
-        float av = 0.f;
-        if (idx >= 0) av = a.in ? a.in[(size_t)idx * a.ldi] : a.in_const;
-        const float bv = valid ? a.Wu[k * 16 + r] : 0.f;
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[0], 0, 0, 0);
-      } else {
-        const int kk = valid ? (int)(((float)j + 0.5f) * a.inv_upk) : 0;
-        const int c4 = valid ? j - kk * a.upk : 0;
-        const int k = (int)kl[kk];
-        int idx = -1;
-        if (valid && rvalid) idx = a.nbr ? a.nbr[(size_t)k * a.ldn + row] : row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx >= 0) v = *reinterpret_cast<const float4 *>(a.in + (size_t)idx * a.ldi + 4 * c4);
-        const float4 *wp = reinterpret_cast<const float4 *>(a.Wu) + ((size_t)(k * a.upk + c4) * a.NT + nt0) * 16 + r;
-        float4 b[NTW];
+    // offsets [kc, kc + nkc) of the list cover this wave's units [j0, j1)
+    const int kk_end = j1 > j0 ? (j1 - 1) / upk + 1 : 0;
+    for (int kc = j1 > j0 ? j0 / upk : 0; kc < kk_end; kc += KCHUNK) {
+      const int nkc = min(KCHUNK, kk_end - kc);
+      // ---- stage neighbour rows of the chunk: ix[kkl*16 + rr]
+      __builtin_amdgcn_wave_barrier();
+      for (int t = lane; t < nkc * 16; t += 64) {
+        const int row = row0 + (t & 15);
+        int v = -1;
+        if (row < count) v = a.nbr ? a.nbr[(size_t)kl[kc + (t >> 4)] * a.ldn + row] : row;
+        ix[t] = v;
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int ju0 = max(j0, kc * upk), ju1 = min(j1, (kc + nkc) * upk);
+      for (int jb = ju0; jb < ju1; jb += 4 * G) {
+        if (CIN1) {
+          float av[G], bv[G];
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) b[nt] = valid ? wp[nt * 16] : make_float4(0.f, 0.f, 0.f, 0.f);
+          for (int g = 0; g < G; ++g) {
+            const int j = jb + 4 * g + q;
+            const bool valid = j < ju1;
+            const int idx = valid ? ix[(j - kc) * 16 + r] : -1;
+            const int k = valid ? (int)kl[j] : 0;
+            av[g] = 0.f;
+            if (idx >= 0) av[g] = a.in ? a.in[(size_t)idx * a.ldi] : a.in_const;
+            bv[g] = valid ? a.Wu[k * 16 + r] : 0.f;
+          }
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, b[nt].x, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, b[nt].y, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, b[nt].z, acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, b[nt].w, acc[nt], 0, 0, 0);
+          for (int g = 0; g < G; ++g) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], bv[g], acc[0], 0, 0, 0);
+        } else {
+          float4 v[G];
+          float4 b[G][NTW];
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            const int j = jb + 4 * g + q;
+            const bool valid = j < ju1;
+            const int kk = valid ? (int)(((float)j + 0.5f) * a.inv_upk) : kc;
+            const int c4 = valid ? j - kk * upk : 0;
+            const int idx = valid ? ix[(kk - kc) * 16 + r] : -1;
+            const int k = (int)kl[kk];
+            v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx >= 0) v[g] = *reinterpret_cast<const float4 *>(a.in + (size_t)idx * a.ldi + 4 * c4);
+            const float4 *wp = reinterpret_cast<const float4 *>(a.Wu) + ((size_t)(k * upk + c4) * a.NT + nt0) * 16 + r;
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) b[g][nt] = valid ? wp[nt * 16] : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].x, b[g][nt].x, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].y, b[g][nt].y, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].z, b[g][nt].z, acc[nt], 0, 0, 0);
+              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].w, b[g][nt].w, acc[nt], 0, 0, 0);
+            }
+          }
         }
       }
     }
@@ -1491,13 +1524,13 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   if (gx > 4096) gx = 4096;
   const dim3 grid((unsigned)gx, (unsigned)(a.NT / g.ntw), (unsigned)g.S);
   if (cs.cin == 1)
-    hipLaunchKernelGGL((k_conv<1, true>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv<1, true, 4, 8>), grid, dim3(256), 0, st, a);
   else if (g.ntw == 1)
-    hipLaunchKernelGGL((k_conv<1, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv<1, false, 3, 8>), grid, dim3(256), 0, st, a);
   else if (g.ntw == 2)
-    hipLaunchKernelGGL((k_conv<2, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv<2, false, 2, 6>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k_conv<4, false>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv<4, false, 2, 4>), grid, dim3(256), 0, st, a);
   if (g.S > 1) hipLaunchKernelGGL(k_reduce_epilogue, dim3((unsigned)(gx < 256 ? gx : 256)), dim3(256), 0, st, a);
   return SPS_OK;
 }
@@ -1999,6 +2032,19 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
   unsigned long long h[128];
   HIP_TRY(hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost));
   for (int k = 0; k < K; ++k) pairs_host[k] = (int64_t)h[k];
+  return SPS_OK;
+}
+
+int sps_get_tile_masks(sps_ctx *c, int which, uint32_t *masks_dev, int64_t *n_tiles) {
+  if (!c || !n_tiles || which < 0 || which > 5) return fail(SPS_ERR_INVALID, "bad arguments");
+  int64_t cnt[SPS_NUM_LEVELS];
+  int rc = sps_level_counts(c, cnt);
+  if (rc != SPS_OK) return rc;
+  const int level = which == 5 ? 0 : which;
+  *n_tiles = (cnt[level] + 15) / 16;
+  const uint32_t *src = which == 5 ? c->tm5 : c->lv[which].tm3;
+  if (masks_dev && *n_tiles > 0)
+    HIP_TRY(hipMemcpy(masks_dev, src, (size_t)*n_tiles * 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
   return SPS_OK;
 }
 
