@@ -44,7 +44,7 @@ extern "C" {
 #define SPS_T_MIN (-16)
 #define SPS_T_MAX (15)
 #define SPS_BATCH_MAX (30)
-#define SPS_MAX_POINTS (1 << 24) /* rows per forward / submap call */
+#define SPS_MAX_POINTS (1 << 23) /* rows per forward / submap call (32-bit byte offsets into [rows,96] f32) */
 
 typedef struct sps_ctx sps_ctx;
 

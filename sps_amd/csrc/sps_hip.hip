@@ -693,7 +693,8 @@ struct ConvArgs {
   int K, cin, cout, NT, upk;
   int relu, S;
   float inv_upk;
-  float in_const;  // cin == 1: constant input feature (0.5, models.py:22) when in == null
+  float in_const;  // conv0: the constant input feature (0.5, models.py:22)
+  uint32_t in_bytes, wu_bytes;  // extents of `in` / `Wu` for the buffer descriptors
 };
 
 // Output-stationary sparse convolution on f32 MFMA.
@@ -713,12 +714,20 @@ struct ConvArgs {
 //   into LDS by all 64 lanes (independent, coalesced loads); the unit loop then issues the gathers
 //   and weight loads of G groups together before their 4*G*NTW MFMAs, so a wave has G (not 1)
 //   dependent-load round trips in flight.
+//   Instruction diet (the v2 kernel issued 11.6 VALU per MFMA, profiles/round1_pmc): LDS holds BYTE
+//   OFFSETS (row * ld * 4, k * bytes-per-offset); gathers and weight loads are buffer_load_dwordx4
+//   with a 32-bit voffset, so the address arithmetic is one add per load, and an absent neighbour is
+//   the out-of-range offset OOR, for which the hardware returns zeros (no branch, no select); (k, c4)
+//   advance incrementally instead of by division.
 constexpr int KCHUNK = 32;
+constexpr uint32_t OOR = 0xFFFF0000u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NTW, bool CIN1, int G, int MINW>
+template <int NTW, int G, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   __shared__ unsigned char klist[4][128];
-  __shared__ int idx_s[4][KCHUNK * 16];
+  __shared__ uint32_t aoff_s[4][KCHUNK * 16];
+  __shared__ uint32_t woff_s[4][KCHUNK];
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -726,8 +735,15 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const int nt0 = blockIdx.y * NTW;
   const int split = blockIdx.z;
   unsigned char *kl = klist[wave];
-  int *ix = idx_s[wave];
-  const int upk = CIN1 ? 1 : a.upk;
+  uint32_t *ao = aoff_s[wave];
+  uint32_t *wo = woff_s[wave];
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
+  const int upk = a.upk;
+  const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
+  const uint32_t wunit = (uint32_t)a.NT * 256u;            // bytes of one unit's weights (all column tiles)
+  const uint32_t wlane = (uint32_t)nt0 * 256u + (uint32_t)r * 16u;
+  const int kstep = 4 / upk, cstep = 4 % upk;              // unit index += 4 per group
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
     const int row0 = tile * 16;
     // ---- prologue: compact list of present offsets (wave-synchronous LDS)
@@ -761,57 +777,49 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
     const int kk_end = j1 > j0 ? (j1 - 1) / upk + 1 : 0;
     for (int kc = j1 > j0 ? j0 / upk : 0; kc < kk_end; kc += KCHUNK) {
       const int nkc = min(KCHUNK, kk_end - kc);
-      // ---- stage neighbour rows of the chunk: ix[kkl*16 + rr]
+      // ---- stage byte offsets of the chunk's neighbour rows: ao[kkl*16 + rr], and of its weights
       __builtin_amdgcn_wave_barrier();
       for (int t = lane; t < nkc * 16; t += 64) {
         const int row = row0 + (t & 15);
         int v = -1;
         if (row < count) v = a.nbr ? a.nbr[(size_t)kl[kc + (t >> 4)] * a.ldn + row] : row;
-        ix[t] = v;
+        ao[t] = v >= 0 ? (uint32_t)v * ldi4 : OOR;
       }
+      if (lane < nkc) wo[lane] = (uint32_t)kl[kc + lane] * (uint32_t)upk * wunit;
       __builtin_amdgcn_wave_barrier();
       const int ju0 = max(j0, kc * upk), ju1 = min(j1, (kc + nkc) * upk);
+      // this lane's first unit of the chunk
+      int jl = ju0 + q;
+      int kk = (int)(((float)jl + 0.5f) * a.inv_upk);
+      int c4 = jl - kk * upk;
+      kk -= kc;
       for (int jb = ju0; jb < ju1; jb += 4 * G) {
-        if (CIN1) {
-          float av[G], bv[G];
+        u32x4 va[G];
+        u32x4 vb[G][NTW];
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const int j = jb + 4 * g + q;
-            const bool valid = j < ju1;
-            const int idx = valid ? ix[(j - kc) * 16 + r] : -1;
-            const int k = valid ? (int)kl[j] : 0;
-            av[g] = 0.f;
-            if (idx >= 0) av[g] = a.in ? a.in[(size_t)idx * a.ldi] : a.in_const;
-            bv[g] = valid ? a.Wu[k * 16 + r] : 0.f;
+        for (int g = 0; g < G; ++g) {
+          const bool valid = jb + 4 * g + q < ju1;
+          const int kkc = min(kk, KCHUNK - 1);
+          const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
+          const uint32_t ob = valid ? wo[kkc] + (uint32_t)c4 * wunit + wlane : OOR;
+          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+          c4 += cstep;
+          kk += kstep;
+          if (c4 >= upk) {
+            c4 -= upk;
+            ++kk;
           }
+        }
 #pragma unroll
-          for (int g = 0; g < G; ++g) acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[g], bv[g], acc[0], 0, 0, 0);
-        } else {
-          float4 v[G];
-          float4 b[G][NTW];
+        for (int g = 0; g < G; ++g) {
 #pragma unroll
-          for (int g = 0; g < G; ++g) {
-            const int j = jb + 4 * g + q;
-            const bool valid = j < ju1;
-            const int kk = valid ? (int)(((float)j + 0.5f) * a.inv_upk) : kc;
-            const int c4 = valid ? j - kk * upk : 0;
-            const int idx = valid ? ix[(kk - kc) * 16 + r] : -1;
-            const int k = (int)kl[kk];
-            v[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx >= 0) v[g] = *reinterpret_cast<const float4 *>(a.in + (size_t)idx * a.ldi + 4 * c4);
-            const float4 *wp = reinterpret_cast<const float4 *>(a.Wu) + ((size_t)(k * upk + c4) * a.NT + nt0) * 16 + r;
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) b[g][nt] = valid ? wp[nt * 16] : make_float4(0.f, 0.f, 0.f, 0.f);
-          }
-#pragma unroll
-          for (int g = 0; g < G; ++g) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].x, b[g][nt].x, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].y, b[g][nt].y, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].z, b[g][nt].z, acc[nt], 0, 0, 0);
-              acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[g].w, b[g][nt].w, acc[nt], 0, 0, 0);
-            }
+          for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb[g][nt].x), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb[g][nt].y), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb[g][nt].z), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
           }
         }
       }
@@ -841,6 +849,58 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
         a.out[(size_t)ro * a.ldo + col] = y;
       }
     }
+  }
+}
+
+// conv0p1s1 (5x5x5x1, 1 -> 8, minkunet.py:55-62) fused with its kernel map.  The input feature is
+// the constant 0.5 (models.py:22; mean of 0.5s, App. A.4), so only the PRESENCE of each of the 125
+// neighbours matters: out[u] = 0.5 * sum_{k present} W[k], k ascending (App. A.8), then BN + ReLU.
+// One thread per voxel; per (dy,dz) the five dx neighbours live in two adjacent blocks whose
+// occupancy masks give the five presence bits at once; no neighbour table is materialised.
+__global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_out, LevelView L,
+                                                      const float *__restrict__ W, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, float in_const,
+                                                      float *__restrict__ out, int ldo) {
+  __shared__ float4 w_s[125 * 2];
+  for (int i = threadIdx.x; i < 250; i += blockDim.x) w_s[i] = reinterpret_cast<const float4 *>(W)[i];
+  __syncthreads();
+  const int n = *n_out;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
+    const int r = L.vblock[u];
+    const int bit = L.vbit[u];
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const int bo_lo = px < 2 ? -1 : 0;  // the dx run [px-2, px+2] touches blocks bo_lo and bo_lo + 1
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+#pragma unroll 1
+    for (int dz = -2; dz <= 2; ++dz) {
+      const int tz = pz + dz;
+#pragma unroll 1
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int ty = py + dy;
+        const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
+        const int sh = ((tz & 3) << 4) | ((ty & 3) << 2);
+        const int nb0 = L.badj[(size_t)r * 81 + ad0], nb1 = L.badj[(size_t)r * 81 + ad0 + 1];
+        const uint32_t m0 = nb0 >= 0 ? (uint32_t)((L.bmask[nb0] >> sh) & 0xFull) : 0u;
+        const uint32_t m1 = nb1 >= 0 ? (uint32_t)((L.bmask[nb1] >> sh) & 0xFull) : 0u;
+        // window bit i = presence at tx = 4 * bo_lo + i; the run starts at tx = px - 2
+        const uint32_t pres = ((m0 | (m1 << 4)) >> (px - 2 - 4 * bo_lo)) & 0x1Fu;
+        const int k0 = 5 * (dy + 2) + 25 * (dz + 2);
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+          if ((pres >> i) & 1u) {
+            const float4 a0 = w_s[(k0 + i) * 2], a1 = w_s[(k0 + i) * 2 + 1];
+            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+            s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+          }
+      }
+    }
+    const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    float y[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) y[c] = fmaxf(v[c] * in_const * scale[c] + shift[c], 0.f);
+    float4 *o = reinterpret_cast<float4 *>(out + (size_t)u * ldo);
+    o[0] = make_float4(y[0], y[1], y[2], y[3]);
+    o[1] = make_float4(y[4], y[5], y[6], y[7]);
   }
 }
 
@@ -1523,14 +1583,19 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   if (gx < 64) gx = 64;
   if (gx > 4096) gx = 4096;
   const dim3 grid((unsigned)gx, (unsigned)(a.NT / g.ntw), (unsigned)g.S);
-  if (cs.cin == 1)
-    hipLaunchKernelGGL((k_conv<1, true, 4, 8>), grid, dim3(256), 0, st, a);
-  else if (g.ntw == 1)
-    hipLaunchKernelGGL((k_conv<1, false, 3, 8>), grid, dim3(256), 0, st, a);
+  a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)cc.ldi * 4u);
+  a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
+  if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
+    hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 256, 2048)), dim3(256), 0, st, a.n_out,
+                       c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
+    return SPS_OK;
+  }
+  if (g.ntw == 1)
+    hipLaunchKernelGGL((k_conv<1, 4, 8>), grid, dim3(256), 0, st, a);
   else if (g.ntw == 2)
-    hipLaunchKernelGGL((k_conv<2, false, 2, 6>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv<2, 2, 6>), grid, dim3(256), 0, st, a);
   else
-    hipLaunchKernelGGL((k_conv<4, false, 2, 4>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((k_conv<4, 2, 4>), grid, dim3(256), 0, st, a);
   if (g.S > 1) hipLaunchKernelGGL(k_reduce_epilogue, dim3((unsigned)(gx < 256 ? gx : 256)), dim3(256), 0, st, a);
   return SPS_OK;
 }
@@ -1760,7 +1825,7 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   ma.counts = c->counts;
   ma.ldn = cap;
   const int gx = grid_for(cap, 256, 1024);
-  hipLaunchKernelGGL(k_build_nbr5, dim3(gx, 25), dim3(256), 0, st, c->counts + 0, L0.view(), c->nbr5, cap, c->tm5);
+  (void)gx;  // the 5x5x5x1 map is never materialised: conv0 is fused with it (k_conv0_fused)
   hipLaunchKernelGGL(k_build_nbr3, dim3(off, 27), dim3(256), 0, st, ma);
   hipLaunchKernelGGL(k_build_stride_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma);
   prof_mark(c, "maps", st);
@@ -2026,6 +2091,9 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
   const int K = which == 5 ? 125 : 81;
   const int level = which == 5 ? 0 : which;
   const int *nbr = which == 5 ? c->nbr5 : c->lv[which].nbr3;
+  if (which == 5)  // debug only: materialise the 5x5x5x1 table from the (still valid) block tables
+    hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0,
+                       c->lv[0].view(), c->nbr5, c->cap, c->tm5);
   HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
   hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, c->cap,
                      c->counts + level, c->pairs);
