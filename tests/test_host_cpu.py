@@ -1,0 +1,158 @@
+"""CPU-only tests: golden vectors captured from the reference python (tools/capture_goldens.py), the
+host-side mirror of the reference API, the C ABI exports, the roofline bookkeeping."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sps_oracle as O
+from tests.helpers import CFG, net_from_params, state_dict_from_params
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------ goldens from the reference
+def _metric_cases():
+    z = np.load(os.path.join(GOLD, "calculate_metrics.npz"))
+    return [(z[f"gt{i}"], z[f"pred{i}"], z[f"out{i}"]) for i in range(int(z["n"]))]
+
+
+def test_calculate_metrics_matches_reference_goldens():
+    import sps.datasets.util as util
+    from sps_amd.models.models import metrics_from_sums
+    for gt, pred, want in _metric_cases():
+        with np.errstate(all="ignore"):
+            got_oracle = np.asarray(O.calculate_metrics(gt, pred), np.float64)
+            got_host = np.asarray(util.calculate_metrics(gt, pred), np.float64)
+        np.testing.assert_allclose(got_oracle, want, rtol=0, atol=1e-12, equal_nan=True)
+        np.testing.assert_allclose(got_host, want, rtol=0, atol=1e-12, equal_nan=True)
+        # the device path returns confusion counts; the host turns them into the same five numbers
+        tp = np.sum((gt == 1) & (pred == 1)); tn = np.sum((gt == 0) & (pred == 0))
+        fp = np.sum((gt == 0) & (pred == 1)); fn = np.sum((gt == 1) & (pred == 0))
+        m = metrics_from_sums([len(gt), tp, fp, fn, tn, 0.0, 0.0, 0.0])
+        got = np.array([m["precision"], m["recall"], m["f1"], m["accuracy"], m["dIoU"]], np.float64)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_transform_point_cloud_matches_reference_goldens():
+    import sps.datasets.util as util
+    z = np.load(os.path.join(GOLD, "transform.npz"))
+    np.testing.assert_array_equal(util.transform_point_cloud(z["pts"], z["T"]), z["out_T"])
+    np.testing.assert_array_equal(util.transform_point_cloud(z["pts"], z["P"]), z["out_P"])
+    np.testing.assert_allclose(util.inverse_transform_point_cloud(z["out_T"], z["T"]), z["inv_T"], rtol=0, atol=1e-12)
+
+
+def test_bacchus_dataset_and_collate_match_reference_goldens():
+    import sps.datasets.blt_dataset as blt
+    z = np.load(os.path.join(GOLD, "bacchus_dataset.npz"))
+    cfg = {"TRAIN": {"AUGMENTATION": False, "BATCH_SIZE": 2}, "MODEL": {"VOXEL_SIZE": 0.1},
+           "DATA": {"NUM_WORKER": 0, "SHUFFLE": False}}
+    ds = blt.BacchusDataset(cfg, [z["scan0"], z["scan1"]], z["pc_map"])
+    items = [ds[0], ds[1]]
+    assert items[0].dtype == torch.float32
+    np.testing.assert_array_equal(items[0].numpy(), z["item0"])          # same rows, same order, duplicates kept
+    np.testing.assert_array_equal(items[1].numpy(), z["item1"])
+    batch = blt.BacchusModule.collate_fn(items)
+    np.testing.assert_array_equal(batch.numpy(), z["batch"])
+    # the oracle's forward accepts exactly this layout
+    assert batch.shape[1] == 6 and set(np.unique(z["batch"][:, 4])) == {0.0, 1.0}
+
+
+# ------------------------------------------------------------------ host mirror of the reference API
+def test_state_dict_keys_and_strict_load():
+    p = O.random_params(seed=0)
+    net = net_from_params(p)                                  # strict load of reference-named keys
+    sd = net.state_dict()
+    assert len(sd) == 194
+    assert sd["model.MinkUNet.conv0p1s1.kernel"].shape == (125, 1, 8)
+    assert sd["model.MinkUNet.block2.0.downsample.0.kernel"].shape == (8, 16)       # 1x1 kernels are 2-D
+    assert sd["model.MinkUNet.final.bias"].shape == (1, 1)
+    assert sd["model.MinkUNet.convtr4p16s2.kernel"].shape == (8, 64, 64)
+    assert "model.MinkUNet.block1.0.downsample.0.kernel" not in sd                  # resnet.py:98
+    n_conv = sum(v.numel() for k, v in sd.items() if k.endswith(".kernel"))
+    assert n_conv == 1_845_168
+    bad = state_dict_from_params(p); bad.pop("model.MinkUNet.bn0.bn.weight")
+    from sps_amd.models.models import SPSNet
+    with pytest.raises(RuntimeError):
+        SPSNet(CFG).load_state_dict(bad)
+
+
+def test_no_cpu_fallback_and_argument_checks():
+    net = net_from_params(O.random_params(seed=0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.zeros(4, 6))
+    import sps.datasets.util as util
+    with pytest.raises(AssertionError, match="cfg is None"):
+        util.load_model(None, "x")
+    with pytest.raises(AssertionError, match="feature_type need to be either"):
+        util.to_coords_features(torch.zeros(3, 3), "foo", 0.1, device="cpu")
+    cf = util.to_coords_features(torch.tensor([[0.26, -0.26, 1.0]]), "scan", 0.1, device="cpu")
+    assert cf.cloud_coords.tolist() == [[2, -2, 10]] and cf.features.tolist() == [[1.0, 0.0]]   # trunc, one-hot
+    assert util.SCAN_TIMESTAMP == 1 and util.MAP_TIMESTAMP == 0
+    t = util.add_timestamp(torch.zeros(2, 3), 1, "cpu")
+    assert t.shape == (2, 4) and t[:, 3].tolist() == [1.0, 1.0]
+
+
+def test_metrics_from_sums_matches_oracle_predict_metrics():
+    from sps_amd.models.models import metrics_from_sums
+    rng = np.random.default_rng(3)
+    n = 500
+    batch = np.zeros((n, 6), np.float32)
+    batch[:, 4] = rng.integers(0, 2, n)
+    batch[:, 5] = rng.uniform(0, 1, n).astype(np.float32)
+    scores = rng.uniform(0, 1, n).astype(np.float32)
+    want = O.predict_metrics(scores, batch, 0.84)
+    scan = batch[:, 4] == 1
+    s, g = scores[scan], batch[scan, 5]
+    e = np.float32(0.84)
+    pred, gt = (s >= e).astype(int), (g >= e).astype(int)
+    sums = [scan.sum(), np.sum((gt == 1) & (pred == 1)), np.sum((gt == 0) & (pred == 1)),
+            np.sum((gt == 1) & (pred == 0)), np.sum((gt == 0) & (pred == 0)),
+            np.sum((s.astype(np.float64) - g) ** 2), np.sum(g.astype(np.float64)), np.sum(g.astype(np.float64) ** 2)]
+    got = metrics_from_sums(sums)
+    for k in ("loss", "r2", "precision", "recall", "f1", "accuracy", "dIoU"):
+        assert got[k] == pytest.approx(want[k], rel=1e-9, abs=1e-12), k
+
+
+def test_synthetic_scene_is_deterministic_and_sized():
+    from sps_amd import synthetic
+    a = synthetic.small_scene(seed=3, n_scan=500)
+    b = synthetic.small_scene(seed=3, n_scan=500)
+    np.testing.assert_array_equal(a, b)
+    assert a.dtype == np.float32 and a.shape[1] == 6
+    assert (a[:500, 4] == 1).all() and (a[500:, 4] == 0).all() and (a[500:, 5] == 1).all()
+    sub = a[500:, 1:4]
+    np.testing.assert_array_equal(O.quantize(np.pad(sub, ((0, 0), (1, 1))), 0.1)[:, 1:4] >= -10**6, True)
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    """The shared library loads without a GPU and exports exactly what include/sps_hip.h declares."""
+    from sps_amd import _native
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "sps_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sps_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(_native._build.LIB)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libsps_hip.so does not export {name}"
+    assert declared == set(_native.EXPORTS)
+    assert _native.lib.sps_version() >= 100
+    assert _native.lib.sps_weights_numel() == 1_848_785
+    # error path without a GPU: bad arguments are rejected before any device call
+    assert _native.lib.sps_weights_tensor_info(9999, None, 0, None, None) < 0
+    assert b"out of range" in _native.lib.sps_last_error()
+
+
+def test_roofline_bookkeeping_reproduces_survey_numbers():
+    """SURVEY.md App. C sizes -> B_alg ~= 281 MB, F_alg ~= 6.17 GFLOP."""
+    from sps_amd import roofline
+    V = [92808, 43050, 14990, 4735, 1628]
+    pairs3 = [1783098, 932350, 298408, 66931, 24460]
+    w = roofline.algorithmic_work(135000, V, pairs3, 2410226)
+    assert w["flops"] == pytest.approx(6.17e9, rel=0.01)
+    assert w["bytes"] == pytest.approx(281e6, rel=0.03)
+    assert len(w["per_layer"]) == 33
