@@ -190,22 +190,31 @@ def main():
         sd = {k.replace("model.MinkUNet.", ""): v.detach().cpu().numpy() for k, v in net.state_dict().items()
               if "num_batches_tracked" not in k}
         blob = c_oracle.pack_blob(sd)
-        cores = os.cpu_count() or 1
+        host_cores = os.cpu_count() or 1
         coords = np.ascontiguousarray(batch_np[:, :5])
-        t = time.perf_counter()
-        ref, info = c_oracle.forward(blob, coords, CFG["MODEL"]["VOXEL_SIZE"], nthreads=cores, want_details=False)
-        first = time.perf_counter() - t
-        nrep = max(1, min(50, int(args.cpu_seconds / max(first, 1e-3)) - 1))
+        vs = CFG["MODEL"]["VOXEL_SIZE"]
+        # the port's OpenMP loops are fine-grained: on a many-core host more threads is slower, so take
+        # the best of a few thread counts (one scan each) and report the count actually used as `cores`
+        best = None
+        for th in sorted({t for t in (1, 4, 8, 16, 32, 64) if t <= host_cores}):
+            c_oracle.forward(blob, coords, vs, nthreads=th, want_details=False)
+            t = time.perf_counter()
+            ref, info = c_oracle.forward(blob, coords, vs, nthreads=th, want_details=False)
+            dt = time.perf_counter() - t
+            if th == 1:
+                single = dt
+            if best is None or dt < best[1]:
+                best = (th, dt)
+        cores, first = best
+        nrep = max(2, min(400, int(args.cpu_seconds / max(first, 1e-3))))
         t = time.perf_counter()
         for _ in range(nrep):
-            c_oracle.forward(blob, coords, CFG["MODEL"]["VOXEL_SIZE"], nthreads=cores, want_details=False)
+            c_oracle.forward(blob, coords, vs, nthreads=cores, want_details=False)
         per = (time.perf_counter() - t) / nrep
-        t = time.perf_counter()
-        c_oracle.forward(blob, coords, CFG["MODEL"]["VOXEL_SIZE"], nthreads=1, want_details=False)
-        single = time.perf_counter() - t
         cpu = {"value": round(1.0 / per, 3), "unit": "scans/s", "cores": cores, "kind": "port",
                "sample": f"{nrep} repeats of the same config-2 scan ({n_points} rows) through the C restatement of the "
-                         "MinkowskiEngine algorithm (ME itself unavailable), OpenMP on all host cores",
+                         f"MinkowskiEngine algorithm (ME itself unavailable), OpenMP with {cores} threads = the fastest of "
+                         f"1/4/8/16/32/64 on this {host_cores}-core host",
                "single_thread_scans_per_s": round(1.0 / single, 3)}
         s = scores.cpu().numpy()
         e = np.float32(eps)

@@ -695,6 +695,15 @@ struct ConvArgs {
   float inv_upk;
   float in_const;  // conv0: the constant input feature (0.5, models.py:22)
   uint32_t in_bytes, wu_bytes;  // extents of `in` / `Wu` for the buffer descriptors
+  // fused 1x1 "downsample" branch of a BasicBlock (resnet.py:98-108): upk2 extra units read from in2 at
+  // the output row itself, weights stored after the K*upk regular units (pre-scaled, see permute)
+  const float *in2;
+  int ldi2, upk2;
+  uint32_t in2_bytes;
+  // fused `final` 1x1 conv + bias (minkunet.py:152-158, C_out = 1): logits[row] = y[row,:] . fin_w + fin_b
+  const float *fin_w;
+  float *fin_out;
+  float fin_b;
 };
 
 // Output-stationary sparse convolution on f32 MFMA.
@@ -723,7 +732,7 @@ constexpr int KCHUNK = 32;
 constexpr uint32_t OOR = 0xFFFF0000u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-template <int NTW, int G, int MINW>
+template <int NTW, int G, int MINW, bool DS, bool FIN>
 __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   __shared__ unsigned char klist[4][128];
   __shared__ uint32_t aoff_s[4][KCHUNK * 16];
@@ -824,7 +833,58 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
         }
       }
     }
+    // ---- fused residual branch: r = downsample(x) = x[row] @ Wds (identity map), last split only
+    if (DS && split == a.S - 1) {
+      const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in2, 0, (int)a.in2_bytes, 0x00020000);
+      const int row = row0 + r;
+      const uint32_t rowoff = row < count ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) : OOR;
+      const uint32_t wbase = (uint32_t)(a.K * upk) * wunit + wlane;
+      for (int jb = 0; jb < a.upk2; jb += 4 * G) {
+        u32x4 va[G];
+        u32x4 vb[G][NTW];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int j = jb + 4 * g + q;
+          const bool valid = j < a.upk2;
+          const uint32_t oa = valid ? rowoff + (uint32_t)j * 16u : OOR;
+          const uint32_t ob = valid ? wbase + (uint32_t)j * wunit : OOR;
+          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, oa, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb[g][nt].x), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb[g][nt].y), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb[g][nt].z), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
+          }
+        }
+      }
+    }
     // ---- epilogue.  C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+    if (NTW == 1 && FIN) {
+      // block8.conv2 + `final`: the 8 channels of a row sit in lanes r = 0..7 of its 16-lane group
+      const int col = r;
+      const bool cv = col < a.cout;
+      const float sc = cv ? a.scale[col] : 0.f, sh = cv ? a.shift[col] : 0.f, fw = cv ? a.fin_w[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        float y = acc[0][i] * sc + sh;
+        if (a.res && cv && ro < count) y += a.res[(size_t)ro * a.ldr + col];
+        if (a.relu) y = fmaxf(y, 0.f);
+        if (cv && ro < count) a.out[(size_t)ro * a.ldo + col] = y;
+        float t = y * fw;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        if (r == 0 && ro < count) a.fin_out[ro] = t + a.fin_b;
+      }
+      continue;
+    }
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
       const int col = (nt0 + nt) * 16 + r;
@@ -874,7 +934,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
 #pragma unroll 1
     for (int dz = -2; dz <= 2; ++dz) {
       const int tz = pz + dz;
-#pragma unroll 1
+#pragma unroll
       for (int dy = -2; dy <= 2; ++dy) {
         const int ty = py + dy;
         const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
@@ -1150,9 +1210,10 @@ struct ConvSpec {
   int64_t w_off = 0;   // offset of the kernel in the blob (floats)
   int64_t ss_off = 0;  // offset of scale/shift pair in the derived buffer
   int64_t wu_off = 0;  // offset of the unit-major permuted kernel (floats)
+  int ds_cin = 0;      // > 0: this conv2 carries the block's fused 1x1 downsample (C_in of the block)
   int nt() const { return (cout + 15) / 16; }
   int upk() const { return cin / 4; }
-  int64_t wu_numel() const { return cin == 1 ? (int64_t)K * 16 : (int64_t)K * upk() * nt() * 64; }
+  int64_t wu_numel() const { return cin == 1 ? (int64_t)K * 16 : ((int64_t)K * upk() + ds_cin / 4) * nt() * 64; }
 };
 struct BnSpec {
   std::string name;
@@ -1184,6 +1245,7 @@ struct NetSpec {
 void add_block(NetSpec &s, const std::string &name, int cin, int cout) {
   s.convs.push_back({name + ".0.conv1", name + ".0.norm1", 81, cin, cout});
   s.convs.push_back({name + ".0.conv2", name + ".0.norm2", 81, cout, cout});
+  if (cin != cout) s.convs.back().ds_cin = cin;
   s.bns.push_back({name + ".0.norm1", cout});
   s.bns.push_back({name + ".0.norm2", cout});
   if (cin != cout) {  // resnet.py:98
@@ -1321,6 +1383,7 @@ struct sps_ctx {
   uint32_t *tm5 = nullptr;
   void *zero_region = nullptr;  // [counts (16 ints) | all tile masks]: one fill per forward
   size_t zero_bytes = 0;
+  float final_bias = 0.f;
   float *slab = nullptr;     // split-K partial sums
   int64_t slab_stride = 0;
   // feature buffers
@@ -1527,6 +1590,9 @@ struct ConvCall {
   const float *res;
   int ldr;
   int relu;
+  const float *in2 = nullptr;  // fused downsample input (block input x)
+  int ldi2 = 0;
+  bool fin = false;            // fuse the `final` 1x1 conv into the epilogue
 };
 
 // Launch geometry per output level (config-2 sizes: 108k / 43k / 15k / 5k / 1.7k rows).  The fine
@@ -1583,6 +1649,17 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   if (gx < 64) gx = 64;
   if (gx > 4096) gx = 4096;
   const dim3 grid((unsigned)gx, (unsigned)(a.NT / g.ntw), (unsigned)g.S);
+  a.in2 = cc.in2;
+  a.ldi2 = cc.ldi2;
+  a.upk2 = cs.ds_cin / 4;
+  a.in2_bytes = (uint32_t)((size_t)c->cap * (size_t)(cc.ldi2 > 0 ? cc.ldi2 : 1) * 4u);
+  if (cs.ds_cin > 0 && !cc.in2) return fail(SPS_ERR_INVALID, "%s needs the block input for its fused downsample", cc.name);
+  if (cc.fin) {
+    const ConvSpec &fs = s.convs[s.find_conv("final")];
+    a.fin_w = c->blob + fs.w_off;
+    a.fin_b = c->final_bias;
+    a.fin_out = c->logits;
+  }
   a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)cc.ldi * 4u);
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
@@ -1590,19 +1667,33 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
                        c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
     return SPS_OK;
   }
-  if (g.ntw == 1)
-    hipLaunchKernelGGL((k_conv<1, 4, 8>), grid, dim3(256), 0, st, a);
-  else if (g.ntw == 2)
-    hipLaunchKernelGGL((k_conv<2, 2, 6>), grid, dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL((k_conv<4, 2, 4>), grid, dim3(256), 0, st, a);
+  const bool ds = cs.ds_cin > 0;
+  if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
+  if (g.ntw == 1) {
+    if (cc.fin)
+      hipLaunchKernelGGL((k_conv<1, 3, 7, true, true>), grid, dim3(256), 0, st, a);
+    else if (ds)
+      hipLaunchKernelGGL((k_conv<1, 3, 8, true, false>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv<1, 4, 8, false, false>), grid, dim3(256), 0, st, a);
+  } else if (g.ntw == 2) {
+    if (ds)
+      hipLaunchKernelGGL((k_conv<2, 2, 6, true, false>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv<2, 2, 6, false, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (ds)
+      hipLaunchKernelGGL((k_conv<4, 2, 4, true, false>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv<4, 2, 4, false, false>), grid, dim3(256), 0, st, a);
+  }
   if (g.S > 1) hipLaunchKernelGGL(k_reduce_epilogue, dim3((unsigned)(gx < 256 ? gx : 256)), dim3(256), 0, st, a);
   return SPS_OK;
 }
 
 // Host-side permutation of one kernel [K][cin][cout] into the unit-major MFMA B-fragment order
 // Wu[u][nt][n][s] = W[k][4*c4 + s][16*nt + n], u = k*upk + c4 (columns zero padded to 16*NT).
-void permute_weights(const ConvSpec &cs, const float *W, float *Wu) {
+void permute_weights(const ConvSpec &cs, const float *W, float *Wu, const float *colscale = nullptr) {
   if (cs.cin == 1) {
     for (int k = 0; k < cs.K; ++k)
       for (int n = 0; n < 16; ++n) Wu[k * 16 + n] = n < cs.cout ? W[(size_t)k * cs.cout + n] : 0.f;
@@ -1616,7 +1707,8 @@ void permute_weights(const ConvSpec &cs, const float *W, float *Wu) {
         for (int n = 0; n < 16; ++n)
           for (int sidx = 0; sidx < 4; ++sidx) {
             const int col = nt * 16 + n;
-            const float v = col < cs.cout ? W[((size_t)k * cs.cin + 4 * c4 + sidx) * cs.cout + col] : 0.f;
+            float v = col < cs.cout ? W[((size_t)k * cs.cin + 4 * c4 + sidx) * cs.cout + col] : 0.f;
+            if (colscale && col < cs.cout) v *= colscale[col];
             Wu[(((size_t)u * NT + nt) * 16 + n) * 4 + sidx] = v;
           }
     }
@@ -1739,7 +1831,37 @@ int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) {
     }
   }
   std::vector<float> wu((size_t)s.wu_numel);
-  for (const ConvSpec &cs : s.convs) permute_weights(cs, blob + cs.w_off, wu.data() + cs.wu_off);
+  for (const ConvSpec &cs : s.convs) {
+    if (cs.ds_cin == 0) {
+      permute_weights(cs, blob + cs.w_off, wu.data() + cs.wu_off);
+      continue;
+    }
+    // conv2 of a block with a 1x1 downsample branch: out = relu(bn2(conv2(y)) + bn_ds(x @ Wds)).
+    // Both BN scales go into the weights (columns of W2 by scale2, of Wds by scale_ds), the extra
+    // units follow the K*upk regular ones, and the epilogue becomes acc + (shift2 + shift_ds).
+    std::string dsname = cs.name;
+    dsname.replace(dsname.find(".conv2"), 6, ".downsample.0");
+    const ConvSpec &ds = s.convs[s.find_conv(dsname)];
+    float *sc2 = ss.data() + cs.ss_off, *sh2 = sc2 + cs.cout;
+    const float *scd = ss.data() + ds.ss_off, *shd = scd + ds.cout;
+    permute_weights(cs, blob + cs.w_off, wu.data() + cs.wu_off, sc2);
+    const int NT = cs.nt();
+    float *ext = wu.data() + cs.wu_off + (size_t)cs.K * cs.upk() * NT * 64;
+    const float *Wd = blob + ds.w_off;  // [cin_ds][cout]
+    for (int c4 = 0; c4 < ds.cin / 4; ++c4)
+      for (int nt = 0; nt < NT; ++nt)
+        for (int n = 0; n < 16; ++n)
+          for (int sidx = 0; sidx < 4; ++sidx) {
+            const int col = nt * 16 + n;
+            ext[(((size_t)c4 * NT + nt) * 16 + n) * 4 + sidx] =
+                col < cs.cout ? Wd[(size_t)(4 * c4 + sidx) * ds.cout + col] * scd[col] : 0.f;
+          }
+    for (int j = 0; j < cs.cout; ++j) {
+      sh2[j] += shd[j];
+      sc2[j] = 1.f;
+    }
+  }
+  c->final_bias = blob[s.bias_off];
   HIP_TRY(hipMemcpy(c->wu, wu.data(), wu.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->blob, blob, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -1838,33 +1960,25 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
       {"block1.0.conv2", c->b1t, 8, c->cat7 + 16, 24, Map{lv[1].nbr3, lv[1].tm3}, 1, c->x1, 8, 1},
       {"conv2p2s2", c->cat7 + 16, 24, c->x2, 8, Map{lv[2].down, lv[2].tmdown}, 2, nullptr, 0, 1},
       {"block2.0.conv1", c->x2, 8, c->b2t, 16, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
-      {"block2.0.downsample.0", c->x2, 8, c->b2r, 16, Map{nullptr, nullptr}, 2, nullptr, 0, 0},
-      {"block2.0.conv2", c->b2t, 16, c->cat6 + 32, 48, Map{lv[2].nbr3, lv[2].tm3}, 2, c->b2r, 16, 1},
+      {"block2.0.conv2", c->b2t, 16, c->cat6 + 32, 48, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1, c->x2, 8},
       {"conv3p4s2", c->cat6 + 32, 48, c->x3, 16, Map{lv[3].down, lv[3].tmdown}, 3, nullptr, 0, 1},
       {"block3.0.conv1", c->x3, 16, c->b3t, 32, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
-      {"block3.0.downsample.0", c->x3, 16, c->b3r, 32, Map{nullptr, nullptr}, 3, nullptr, 0, 0},
-      {"block3.0.conv2", c->b3t, 32, c->cat5 + 64, 96, Map{lv[3].nbr3, lv[3].tm3}, 3, c->b3r, 32, 1},
+      {"block3.0.conv2", c->b3t, 32, c->cat5 + 64, 96, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->x3, 16},
       {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, Map{lv[4].down, lv[4].tmdown}, 4, nullptr, 0, 1},
       {"block4.0.conv1", c->x4, 32, c->b4t, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1},
-      {"block4.0.downsample.0", c->x4, 32, c->b4r, 64, Map{nullptr, nullptr}, 4, nullptr, 0, 0},
-      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, c->b4r, 64, 1},
+      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1, c->x4, 32},
       {"convtr4p16s2", c->b4o, 64, c->cat5, 96, Map{lv[4].up, lv[4].tmup}, 3, nullptr, 0, 1},
       {"block5.0.conv1", c->cat5, 96, c->b5t, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
-      {"block5.0.downsample.0", c->cat5, 96, c->b5r, 64, Map{nullptr, nullptr}, 3, nullptr, 0, 0},
-      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, c->b5r, 64, 1},
+      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->cat5, 96},
       {"convtr5p8s2", c->b5o, 64, c->cat6, 48, Map{lv[3].up, lv[3].tmup}, 2, nullptr, 0, 1},
       {"block6.0.conv1", c->cat6, 48, c->b6t, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
-      {"block6.0.downsample.0", c->cat6, 48, c->b6r, 32, Map{nullptr, nullptr}, 2, nullptr, 0, 0},
-      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, c->b6r, 32, 1},
+      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1, c->cat6, 48},
       {"convtr6p4s2", c->b6o, 32, c->cat7, 24, Map{lv[2].up, lv[2].tmup}, 1, nullptr, 0, 1},
       {"block7.0.conv1", c->cat7, 24, c->b7t, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1},
-      {"block7.0.downsample.0", c->cat7, 24, c->b7r, 16, Map{nullptr, nullptr}, 1, nullptr, 0, 0},
-      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, c->b7r, 16, 1},
+      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1, c->cat7, 24},
       {"convtr7p2s2", c->b7o, 16, c->cat8, 16, Map{lv[1].up, lv[1].tmup}, 0, nullptr, 0, 1},
       {"block8.0.conv1", c->cat8, 16, c->b8t, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1},
-      {"block8.0.downsample.0", c->cat8, 16, c->b8r, 8, Map{nullptr, nullptr}, 0, nullptr, 0, 0},
-      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, c->b8r, 8, 1},
-      {"final", c->b8o, 8, c->logits, 1, Map{nullptr, nullptr}, 0, nullptr, 0, 0},
+      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1, c->cat8, 16, true},
   };
   for (const ConvCall &cc : calls) {
     int rc = run_conv(c, cc, st);
