@@ -172,6 +172,44 @@ __device__ inline uint64_t bkey_pack(uint32_t b, uint32_t tt, uint32_t bx, uint3
 
 constexpr int NLV = SPS_NUM_LEVELS;
 
+// Insert `key` (when ok) into the block hash and OR the 64-bit contribution (lo, hi) into its mask,
+// min the source index `src` into `first`.  Runs of consecutive lanes with the same key are merged:
+// the first lane of a run issues the three atomics for the whole run (segmented OR-scan over the
+// run); all runs proceed in parallel.  Consecutive LiDAR returns / consecutive blocks mostly share
+// their block / ancestor, so this cuts the atomic traffic several-fold.  Must be called by ALL lanes
+// of the wave with src increasing with the lane index.  Returns the slot (valid where ok).
+__device__ inline int wave_run_insert(const BHash &h, uint64_t key, bool ok, uint32_t olo, uint32_t ohi, int src) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+  const uint32_t plo = __shfl_up(klo, 1, 64), phi = __shfl_up(khi, 1, 64);
+  const int pok = __shfl_up((int)ok, 1, 64);
+  const bool head = !(lane > 0 && ok && pok && plo == klo && phi == khi);
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long le = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+  const int rid = __popcll(le);
+  const int head_lane = 63 - __clzll((long long)le);
+  if (!ok) {
+    olo = 0u;
+    ohi = 0u;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t vlo = __shfl_down(olo, o, 64), vhi = __shfl_down(ohi, o, 64);
+    const int r2 = __shfl_down(rid, o, 64);
+    if (lane + o < 64 && r2 == rid) {
+      olo |= vlo;
+      ohi |= vhi;
+    }
+  }
+  int slot = -1;
+  if (head && ok) {
+    slot = bhash_insert(h, key);
+    atomicOr(&h.mask[slot], ((unsigned long long)ohi << 32) | olo);
+    atomicMin(&h.first[slot], src);  // the head is the run's smallest source index
+  }
+  return __shfl(slot, head_lane, 64);
+}
+
 // level 0: quantise points (models.py:21: f32 true division by [1,vs,vs,vs,1]; ME floor), insert the
 // point's block, set its occupancy bit.  Consecutive LiDAR returns mostly fall into the same block:
 // the wave elects one lane per distinct block, which issues the three atomics for the whole group.
@@ -201,34 +239,7 @@ __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restric
       atomicOr(err, 1);
     }
   }
-  // Runs of consecutive lanes with the same block: the first lane of a run issues the atomics for the
-  // whole run (segmented OR-scan over the run); all runs proceed in parallel.
-  const int lane = threadIdx.x & 63;
-  const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-  const uint32_t plo = __shfl_up(klo, 1, 64), phi = __shfl_up(khi, 1, 64);
-  const int pok = __shfl_up((int)ok, 1, 64);
-  const bool head = !(lane > 0 && ok && pok && plo == klo && phi == khi);
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long le = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
-  const int rid = __popcll(le);
-  const int head_lane = 63 - __clzll((long long)le);
-  uint32_t olo = (ok && bit < 32) ? (1u << bit) : 0u, ohi = (ok && bit >= 32) ? (1u << (bit - 32)) : 0u;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t vlo = __shfl_down(olo, o, 64), vhi = __shfl_down(ohi, o, 64);
-    const int r2 = __shfl_down(rid, o, 64);
-    if (lane + o < 64 && r2 == rid) {
-      olo |= vlo;
-      ohi |= vhi;
-    }
-  }
-  int slot = -1;
-  if (head && ok) {
-    slot = bhash_insert(h, key);
-    atomicOr(&h.mask[slot], ((unsigned long long)ohi << 32) | olo);
-    atomicMin(&h.first[slot], p);  // the head is the run's smallest point index
-  }
-  slot = __shfl(slot, head_lane, 64);
+  const int slot = wave_run_insert(h, key, ok, bit < 32 ? (1u << bit) : 0u, bit >= 32 ? (1u << (bit - 32)) : 0u, p);
   if (p < n) {
     sslot[p] = ok ? slot : -1;
     sbit[p] = (unsigned char)bit;
@@ -257,35 +268,38 @@ struct PyramidArgs {
 // level (App. A.9: floor(c / 2ts) * 2ts applied l times = a right shift of the biased coordinate).
 // A level-0 block covers 2x2x2 level-1 voxels (an octant of its parent block) and exactly one voxel
 // of levels 2..4.
-__global__ void k_blocks_to_ancestors(PyramidArgs a) {
+__global__ __launch_bounds__(256) void k_blocks_to_ancestors(PyramidArgs a) {
   const int n = a.counts[8];
   const int l = 1 + (int)blockIdx.y;
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-    const uint64_t key = a.bkey[0][r];
-    const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF),
-                   bz = (uint32_t)((key >> 36) & 0x3FFFF);
-    const uint64_t bt = key & (0x3FFull << 54);
-    const uint64_t pkey = bt | ((uint64_t)(bz >> l) << 36) | ((uint64_t)(by >> l) << 18) | (uint64_t)(bx >> l);
+  const int nround = (n + 255) & ~255;  // whole waves enter wave_run_insert
+  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nround; r += gridDim.x * blockDim.x) {
+    const bool ok = r < n;
+    uint64_t pkey = KEY_EMPTY;
     unsigned long long pm = 0;
-    if (l == 1) {
-      const unsigned long long m = a.bmask[0][r];
-      const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
+    if (ok) {
+      const uint64_t key = a.bkey[0][r];
+      const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF),
+                     bz = (uint32_t)((key >> 36) & 0x3FFFF);
+      const uint64_t bt = key & (0x3FFull << 54);
+      pkey = bt | ((uint64_t)(bz >> l) << 36) | ((uint64_t)(by >> l) << 18) | (uint64_t)(bx >> l);
+      if (l == 1) {
+        const unsigned long long m = a.bmask[0][r];
+        const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+          for (int j = 0; j < 2; ++j)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
-            if (m & (0x0000000000330033ull << (2 * i + 8 * j + 32 * k)))
-              pm |= 1ull << ((2 * oz + k) * 16 + (2 * oy + j) * 4 + (2 * ox + i));
-    } else {
-      const uint32_t px = (bx >> (l - 2)) & 3, py = (by >> (l - 2)) & 3, pz = (bz >> (l - 2)) & 3;
-      pm = 1ull << ((pz << 4) | (py << 2) | px);
+            for (int i = 0; i < 2; ++i)
+              if (m & (0x0000000000330033ull << (2 * i + 8 * j + 32 * k)))
+                pm |= 1ull << ((2 * oz + k) * 16 + (2 * oy + j) * 4 + (2 * ox + i));
+      } else {
+        const uint32_t px = (bx >> (l - 2)) & 3, py = (by >> (l - 2)) & 3, pz = (bz >> (l - 2)) & 3;
+        pm = 1ull << ((pz << 4) | (py << 2) | px);
+      }
     }
-    const int s = bhash_insert(a.h[l], pkey);
-    atomicOr(&a.h[l].mask[s], pm);
-    atomicMin(&a.h[l].first[s], r);
-    a.sslot[l][r] = s;
+    const int sl = wave_run_insert(a.h[l], pkey, ok, (uint32_t)pm, (uint32_t)(pm >> 32), r);
+    if (ok) a.sslot[l][r] = sl;
   }
 }
 
@@ -694,7 +708,7 @@ struct ConvArgs {
   int relu, S;
   float inv_upk;
   float in_const;  // conv0: the constant input feature (0.5, models.py:22)
-  uint32_t in_bytes, wu_bytes;  // extents of `in` / `Wu` for the buffer descriptors
+  uint32_t in_bytes, wu_bytes, nbr_bytes;  // extents of `in` / `Wu` / `nbr` for the buffer descriptors
   // fused 1x1 "downsample" branch of a BasicBlock (resnet.py:98-108): upk2 extra units read from in2 at
   // the output row itself, weights stored after the K*upk regular units (pre-scaled, see permute)
   const float *in2;
@@ -748,6 +762,8 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   uint32_t *wo = woff_s[wave];
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
+  const uint32_t ldn32 = (uint32_t)a.ldn;
   const int upk = a.upk;
   const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
   const uint32_t wunit = (uint32_t)a.NT * 256u;            // bytes of one unit's weights (all column tiles)
@@ -786,13 +802,35 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
     const int kk_end = j1 > j0 ? (j1 - 1) / upk + 1 : 0;
     for (int kc = j1 > j0 ? j0 / upk : 0; kc < kk_end; kc += KCHUNK) {
       const int nkc = min(KCHUNK, kk_end - kc);
-      // ---- stage byte offsets of the chunk's neighbour rows: ao[kkl*16 + rr], and of its weights
+      // ---- stage byte offsets of the chunk's neighbour rows: ao[kkl*16 + rr], and of its weights.
+      // Lane (q, r) owns row r for the offsets kc + q + 4i: all NST loads are issued before any is used.
       __builtin_amdgcn_wave_barrier();
-      for (int t = lane; t < nkc * 16; t += 64) {
-        const int row = row0 + (t & 15);
-        int v = -1;
-        if (row < count) v = a.nbr ? a.nbr[(size_t)kl[kc + (t >> 4)] * a.ldn + row] : row;
-        ao[t] = v >= 0 ? (uint32_t)v * ldi4 : OOR;
+      {
+        constexpr int NST = KCHUNK * 16 / 64;
+        const int row = row0 + r;
+        const bool rv = row < count;
+        int vals[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int kkl = q + 4 * i;
+          const bool act = rv && kkl < nkc;
+          if (a.nbr) {
+#if defined(SPS_ABLATE_STAGE)
+            vals[i] = act ? row : -1;
+#else
+            const uint32_t off = act ? ((uint32_t)kl[kc + kkl] * ldn32 + (uint32_t)row) * 4u : OOR;
+            vals[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
+#endif
+          } else {
+            vals[i] = row;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int kkl = q + 4 * i;
+          const bool act = rv && kkl < nkc;
+          if (kkl < nkc) ao[kkl * 16 + r] = (act && vals[i] >= 0) ? (uint32_t)vals[i] * ldi4 : OOR;
+        }
       }
       if (lane < nkc) wo[lane] = (uint32_t)kl[kc + lane] * (uint32_t)upk * wunit;
       __builtin_amdgcn_wave_barrier();
@@ -809,18 +847,35 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
         for (int g = 0; g < G; ++g) {
           const bool valid = jb + 4 * g + q < ju1;
           const int kkc = min(kk, KCHUNK - 1);
+#if defined(SPS_ABLATE_A)
+          const uint32_t oa = OOR;
+          (void)ao;
+#else
           const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
+#endif
+#if defined(SPS_ABLATE_B)
+          const uint32_t ob = OOR;
+#else
           const uint32_t ob = valid ? wo[kkc] + (uint32_t)c4 * wunit + wlane : OOR;
+#endif
           va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
 #pragma unroll
           for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
           c4 += cstep;
           kk += kstep;
-          if (c4 >= upk) {
-            c4 -= upk;
-            ++kk;
-          }
+          const int wrap = c4 >= upk ? 1 : 0;   // branch-free carry of the (k, c4) counter
+          c4 -= wrap ? upk : 0;
+          kk += wrap;
         }
+#if defined(SPS_ABLATE_MFMA)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          asm volatile("" ::"v"(va[g].x), "v"(va[g].y), "v"(va[g].z), "v"(va[g].w));
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            asm volatile("" ::"v"(vb[g][nt].x), "v"(vb[g][nt].y), "v"(vb[g][nt].z), "v"(vb[g][nt].w));
+        }
+#else
 #pragma unroll
         for (int g = 0; g < G; ++g) {
 #pragma unroll
@@ -831,6 +886,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
             acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
           }
         }
+#endif
       }
     }
     // ---- fused residual branch: r = downsample(x) = x[row] @ Wds (identity map), last split only
@@ -1604,12 +1660,13 @@ struct Geometry {
 };
 Geometry conv_geometry(int level, int K, int cin, int nt) {
   if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
+  const int upk = cin / 4;  // ~30 present offsets x upk units per tile
   switch (level) {
     case 0: return {nt, 1};
     case 1: return {nt, 1};
-    case 2: return {1, 2};
-    case 3: return {1, 4};
-    default: return {1, 8};
+    case 2: return {1, upk <= 8 ? 1 : 2};
+    case 3: return {1, upk <= 4 ? 1 : (upk <= 8 ? 2 : 4)};
+    default: return {1, upk <= 8 ? 2 : 4};
   }
 }
 
@@ -1662,6 +1719,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   }
   a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)cc.ldi * 4u);
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
+  a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->cap * 4u);
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
     hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 256, 2048)), dim3(256), 0, st, a.n_out,
                        c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
@@ -1673,9 +1731,9 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     if (cc.fin)
       hipLaunchKernelGGL((k_conv<1, 3, 7, true, true>), grid, dim3(256), 0, st, a);
     else if (ds)
-      hipLaunchKernelGGL((k_conv<1, 3, 8, true, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<1, 3, 7, true, false>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<1, 4, 8, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<1, 4, 7, false, false>), grid, dim3(256), 0, st, a);
   } else if (g.ntw == 2) {
     if (ds)
       hipLaunchKernelGGL((k_conv<2, 2, 6, true, false>), grid, dim3(256), 0, st, a);
@@ -1927,7 +1985,8 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   (void)gsl;
   prof_mark(c, "pyramid", st);
   // ---- kernel maps
-  hipLaunchKernelGGL(k_block_adj, dim3(grid_for(cap >> 1, 256, 1024), NLV), dim3(256), 0, st, pa);
+  // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
+  hipLaunchKernelGGL(k_block_adj, dim3(grid_for((cap >> 2) * 81, 256, 16384), NLV), dim3(256), 0, st, pa);
   MapsArgs ma{};
   int off = 0;
   for (int l = 0; l < NLV; ++l) {

@@ -67,14 +67,14 @@ def prune(map_coords_feat=None, scan_coords_feat=None, ds=0.1):
     models._require_device_tensor(sc, "scan coordinates")
     models._require_device_tensor(mc, "map coordinates")
     dev = sc.device.index or 0
-    ctx = models.get_context(dev)
     with torch.cuda.device(sc.device):
         stream = torch.cuda.current_stream().cuda_stream
+        ctx = models.get_context(dev, stream)
         mc32 = mc if (mc.dtype == torch.int32 and mc.stride(1) == 1) else mc.to(torch.int32).contiguous()
         key = (mc.data_ptr(), tuple(mc.shape), mc._version)
-        if _MAP_CACHE.get(dev) != key:
+        if _MAP_CACHE.get(id(ctx)) != key:
             ctx.map_upload_voxels(mc32.data_ptr(), mc32.stride(0), mc32.shape[0], stream)
-            _MAP_CACHE[dev] = key
+            _MAP_CACHE[id(ctx)] = key
         sc32 = sc if (sc.dtype == torch.int32 and sc.stride(1) == 1) else sc.to(torch.int32).contiguous()
         n = sc32.shape[0]
         out = torch.empty((n, 3), dtype=torch.float32, device=sc.device)

@@ -24,14 +24,22 @@ import torch.nn as nn
 from .. import _native
 from .minkunet import CustomMinkUNet
 
-_CONTEXTS: dict[int, "_native.Context"] = {}
+_CONTEXTS: dict[tuple, "_native.Context"] = {}
 
 
-def get_context(device_index: int) -> "_native.Context":
-    """One native context per (process, device)."""
-    ctx = _CONTEXTS.get(device_index)
+def get_context(device_index: int, stream: int | None = None) -> "_native.Context":
+    """One native context per (process, device, stream).
+
+    A context is stream-ordered state (arena, hash tables, weights): work issued on different torch
+    streams gets different contexts, so independent scans can be pipelined on several streams and their
+    many small kernels overlap on the GPU.  ``stream`` is the raw hipStream_t handle (0 = default stream);
+    None = the current torch stream of that device."""
+    if stream is None:
+        stream = torch.cuda.current_stream(device_index).cuda_stream if torch.cuda.is_available() else 0
+    key = (device_index, int(stream))
+    ctx = _CONTEXTS.get(key)
     if ctx is None:
-        ctx = _CONTEXTS[device_index] = _native.Context(device_index)
+        ctx = _CONTEXTS[key] = _native.Context(device_index)
     return ctx
 
 
@@ -49,22 +57,22 @@ class SPSModel(nn.Module):
         self.quantization = torch.Tensor([1.0, voxel_size, voxel_size, voxel_size, 1.0])
         self.MinkUNet = CustomMinkUNet(in_channels=1, out_channels=1, D=4)
         self.sigmoid = nn.Sigmoid()
-        self._loaded_ctx = None          # native context that currently holds this module's weights
+        self._loaded_ctxs = set()        # native contexts that currently hold this module's weights
         # any load_state_dict that reaches the backbone (predict.py:58 or util.py:39) re-uploads
         self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self.mark_weights_dirty())
 
     # ---- weights -> native blob ---------------------------------------------------------
     def mark_weights_dirty(self) -> None:
         """Call after modifying parameters in place; load_state_dict / .cuda() / .to() do it themselves."""
-        self._loaded_ctx = None
+        self._loaded_ctxs = set()
 
     def _apply(self, fn, *args, **kwargs):
-        self._loaded_ctx = None
+        self._loaded_ctxs = set()
         return super()._apply(fn, *args, **kwargs)
 
     def _sync_weights(self, ctx) -> None:
         owner = getattr(ctx, "weights_owner", None)
-        if self._loaded_ctx is ctx and owner is not None and owner() is self:
+        if id(ctx) in self._loaded_ctxs and owner is not None and owner() is self:
             return                       # this module's weights are the ones resident in ctx
         sd = self.MinkUNet.state_dict()
         blob = np.empty(_native.lib.sps_weights_numel(), dtype=np.float32)
@@ -74,8 +82,8 @@ class SPSModel(nn.Module):
                 raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
             blob[off: off + numel] = t.numpy()
         ctx.load_weights(blob.ctypes.data, blob.size)
-        ctx.weights_owner = weakref.ref(self)   # a context is shared by every model on its device
-        self._loaded_ctx = ctx
+        ctx.weights_owner = weakref.ref(self)   # a context is shared by every model on its device/stream
+        self._loaded_ctxs.add(id(ctx))
 
     # ---- forward --------------------------------------------------------------------------
     def forward(self, coordinates: torch.Tensor) -> torch.Tensor:
@@ -87,12 +95,12 @@ class SPSModel(nn.Module):
             coordinates = coordinates.to(torch.float32)
         if coordinates.stride(1) != 1:
             coordinates = coordinates.contiguous()
-        ctx = get_context(coordinates.device.index or 0)
         with torch.cuda.device(coordinates.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            ctx = get_context(coordinates.device.index or 0, stream)
             self._sync_weights(ctx)
             n = coordinates.shape[0]
             scores = torch.empty(n, dtype=torch.float32, device=coordinates.device)
-            stream = torch.cuda.current_stream().cuda_stream
             ctx.forward(coordinates.data_ptr(), coordinates.stride(0) if n else 5, n, self.voxel_size,
                         scores.data_ptr(), stream)
         return scores
@@ -130,9 +138,9 @@ class SPSNet(nn.Module):
         _require_device_tensor(batch, "batch")
         if batch.dtype != torch.float32 or batch.stride(1) != 1:
             batch = batch.to(torch.float32).contiguous()
-        ctx = get_context(batch.device.index or 0)
         with torch.cuda.device(batch.device):
             stream = torch.cuda.current_stream().cuda_stream
+            ctx = get_context(batch.device.index or 0, stream)
             return ctx.metrics(scores.data_ptr(), batch.data_ptr(), batch.stride(0), batch.shape[0],
                                float(self.epsilon), n_batches, stream)
 

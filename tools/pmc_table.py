@@ -2,10 +2,10 @@
 Usage: pmc_table.py <dir> [<dir> ...]   (several passes are merged by layer)"""
 import csv, glob, sys, collections
 sys.path.insert(0, ".")
-names = ["conv0p1s1", "conv1p1s2", "block1.conv1", "block1.conv2", "conv2p2s2", "block2.conv1", "block2.ds", "block2.conv2",
-         "conv3p4s2", "block3.conv1", "block3.ds", "block3.conv2", "conv4p8s2", "block4.conv1", "block4.ds", "block4.conv2",
-         "convtr4", "block5.conv1", "block5.ds", "block5.conv2", "convtr5", "block6.conv1", "block6.ds", "block6.conv2",
-         "convtr6", "block7.conv1", "block7.ds", "block7.conv2", "convtr7", "block8.conv1", "block8.ds", "block8.conv2", "final"]
+names = ["conv1p1s2", "block1.conv1", "block1.conv2", "conv2p2s2", "block2.conv1", "block2.conv2",
+         "conv3p4s2", "block3.conv1", "block3.conv2", "conv4p8s2", "block4.conv1", "block4.conv2",
+         "convtr4", "block5.conv1", "block5.conv2", "convtr5", "block6.conv1", "block6.conv2",
+         "convtr6", "block7.conv1", "block7.conv2", "convtr7", "block8.conv1", "block8.conv2"]
 table = collections.defaultdict(lambda: collections.defaultdict(list))
 other = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
