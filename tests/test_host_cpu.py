@@ -156,3 +156,54 @@ def test_roofline_bookkeeping_reproduces_survey_numbers():
     assert w["flops"] == pytest.approx(6.17e9, rel=0.01)
     assert w["bytes"] == pytest.approx(281e6, rel=0.03)
     assert len(w["per_layer"]) == 33
+
+
+# ------------------------------------------------------------------ $DATA tree reader (blt_dataset.py:26-100)
+def _write_data_tree(root, n_scans=3, seq="20220629"):
+    rng = np.random.default_rng(7)
+    os.makedirs(os.path.join(root, "maps"))
+    os.makedirs(os.path.join(root, "sequence", seq, "scans"))
+    os.makedirs(os.path.join(root, "sequence", seq, "poses"))
+    pc_map = np.concatenate([rng.uniform(-4, 4, (3000, 3)), rng.uniform(0, 1, (3000, 2))], 1)   # 5 columns: first 4 used
+    np.save(os.path.join(root, "maps", "base_map.asc.npy"), pc_map)
+    ang = 0.3
+    T_map = np.array([[np.cos(ang), -np.sin(ang), 0, 0.5], [np.sin(ang), np.cos(ang), 0, -0.25], [0, 0, 1, 0.1], [0, 0, 0, 1.0]])
+    np.savetxt(os.path.join(root, "sequence", seq, "map_transform"), T_map, delimiter=",")
+    scans, poses = [], []
+    for i in range(n_scans):
+        pose = np.eye(4); pose[:3, 3] = [0.2 * i, -0.1 * i, 0.0]
+        world = pc_map[rng.choice(len(pc_map), 120, replace=False), :3] + rng.normal(0, 0.03, (120, 3))
+        sensor = (np.linalg.inv(T_map @ pose) @ np.c_[world, np.ones(len(world))].T).T[:, :3]
+        scan = np.c_[sensor, rng.uniform(0, 1, len(sensor))].astype(np.float64)
+        stamp = f"{1656500000.0 + i:.6f}"
+        np.save(os.path.join(root, "sequence", seq, "scans", stamp + ".npy"), scan)
+        np.savetxt(os.path.join(root, "sequence", seq, "poses", stamp + ".txt"), pose, delimiter=",")
+        scans.append(scan); poses.append(pose)
+    return pc_map, T_map, scans, poses
+
+
+def test_bacchus_module_reads_data_tree(tmp_path, monkeypatch):
+    import sps.datasets.blt_dataset as blt
+    import sps.datasets.util as util
+    pc_map, T_map, scans, poses = _write_data_tree(str(tmp_path))
+    monkeypatch.setenv("DATA", str(tmp_path))
+    cfg = {"DATA": {"SHUFFLE": False, "NUM_WORKER": 0, "SPLIT": {"TRAIN": [], "VAL": [], "TEST": ["20220629"]}},
+           "TRAIN": {"MAP": "base_map.asc.npy", "BATCH_SIZE": 2, "AUGMENTATION": False}, "MODEL": {"VOXEL_SIZE": 0.1}}
+    dm = blt.BacchusModule(cfg, test=True)
+    assert dm.map.shape == (3000, 4) and len(dm.test_scans) == 3
+    # cash_scans: xyz <- T_map . (T_pose . xyz), label column untouched
+    for got, scan, pose in zip(dm.test_scans, scans, poses):
+        want = util.transform_point_cloud(util.transform_point_cloud(scan[:, :3], pose), T_map)
+        np.testing.assert_allclose(got[:, :3], want, rtol=0, atol=1e-12)
+        np.testing.assert_array_equal(got[:, 3], scan[:, 3])
+    dm.setup()
+    batches = list(dm.test_dataloader())
+    assert len(batches) == 2 and batches[0].shape[1] == 6
+    assert set(batches[0][:, 0].tolist()) == {0.0, 1.0} and set(batches[1][:, 0].tolist()) == {0.0}
+    first = batches[0][batches[0][:, 0] == 0]
+    assert (first[:120, 4] == 1).all() and (first[120:, 4] == 0).all() and (first[120:, 5] == 1).all()
+    # the scans were generated from map points: the radius submap must be non-empty
+    assert len(first) > 120
+    with pytest.raises(AssertionError, match="should be the same"):
+        os.remove(sorted((tmp_path / "sequence" / "20220629" / "poses").iterdir())[0])
+        blt.BacchusModule(cfg, test=True)
