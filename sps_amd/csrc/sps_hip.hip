@@ -315,104 +315,97 @@ __device__ inline int block_reduce_sum(int v, int *lds) {
   return tot;
 }
 
-// exclusive scan of `val` over the grid's elements given the per-workgroup totals of an earlier
-// pass: returns this thread's offset.
-__device__ inline int block_exclusive_scan(int val, const int *__restrict__ block_sums, int *lds, int *wave_off) {
-  int part = 0;
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) part += block_sums[i];
-  const int base = block_reduce_sum(part, lds);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int incl = val;
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
+// exclusive scan of the pair (v0, v1) over the grid's elements given the per-workgroup totals
+// (block_sums[2*i], block_sums[2*i+1]) of an earlier pass: returns this thread's two offsets.
+__device__ inline int2 block_exclusive_scan2(int v0, int v1, const int *__restrict__ block_sums, int *lds, int2 *wave_off) {
+  int p0 = 0, p1 = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) {
+    p0 += block_sums[2 * i];
+    p1 += block_sums[2 * i + 1];
   }
-  if (lane == 63) wave_off[wave] = incl;
+  const int base0 = block_reduce_sum(p0, lds);
+  const int base1 = block_reduce_sum(p1, lds);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int i0 = v0, i1 = v1;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t0 = __shfl_up(i0, o, 64), t1 = __shfl_up(i1, o, 64);
+    if (lane >= o) {
+      i0 += t0;
+      i1 += t1;
+    }
+  }
+  if (lane == 63) wave_off[wave] = make_int2(i0, i1);
   __syncthreads();
-  int off = 0;
-  for (int i = 0; i < wave; ++i) off += wave_off[i];
+  int o0 = 0, o1 = 0;
+  for (int i = 0; i < wave; ++i) {
+    o0 += wave_off[i].x;
+    o1 += wave_off[i].y;
+  }
   __syncthreads();
-  return base + off + incl - val;
+  return make_int2(base0 + o0 + i0 - v0, base1 + o1 + i1 - v1);
 }
 
 // Batched over levels lv0 + blockIdx.y.  Sources of level 0 are the n0 points, of levels >= 1 the
-// level-0 blocks.
-// pass A: number of first occurrences per SCAN_BLOCK sources.
+// level-0 blocks.  A source is the FIRST of its block when first[slot] == source index; the block's
+// occupancy mask is already final, so block ranks and voxel row bases are scanned together.
+// pass A: per SCAN_BLOCK sources: number of first occurrences, number of voxels they bring.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(PyramidArgs a, int lv0, int n0) {
   __shared__ int lds[SCAN_BLOCK / 64];
   const int l = lv0 + blockIdx.y;
   const int n = l == 0 ? n0 : a.counts[8];
   if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
   const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  int flag = 0;
+  int flag = 0, cnt = 0;
   if (p < n) {
     const int s = a.sslot[l][p];
-    flag = (s >= 0 && a.h[l].first[s] == p) ? 1 : 0;
+    if (s >= 0 && a.h[l].first[s] == p) {
+      flag = 1;
+      cnt = __popcll(a.h[l].mask[s]);
+    }
   }
-  const int tot = block_reduce_sum(flag, lds);
-  if (threadIdx.x == 0) a.block_sums[l * a.sums_stride + blockIdx.x] = tot;
+  const int t0 = block_reduce_sum(flag, lds);
+  const int t1 = block_reduce_sum(cnt, lds);
+  if (threadIdx.x == 0) {
+    a.block_sums[l * a.sums_stride + 2 * blockIdx.x] = t0;
+    a.block_sums[l * a.sums_stride + 2 * blockIdx.x + 1] = t1;
+  }
 }
 
-// pass B: rank of each block = exclusive scan of the flags; bslot[rank] = hash slot; block count.
+// pass B: block rank and voxel base of every first occurrence; compact per-block arrays; counts.
 __global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv0, int n0) {
   __shared__ int lds[SCAN_BLOCK / 64];
-  __shared__ int wave_off[SCAN_BLOCK / 64];
+  __shared__ int2 wave_off[SCAN_BLOCK / 64];
   const int l = lv0 + blockIdx.y;
   const int n = l == 0 ? n0 : a.counts[8];
   const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   if ((int)blockIdx.x >= nwg) return;  // counts were zeroed by the reset
   const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  int s = -1, flag = 0;
+  int s = -1, flag = 0, cnt = 0;
+  unsigned long long m = 0;
   if (p < n) {
     s = a.sslot[l][p];
-    flag = (s >= 0 && a.h[l].first[s] == p) ? 1 : 0;
+    if (s >= 0 && a.h[l].first[s] == p) {
+      flag = 1;
+      m = a.h[l].mask[s];
+      cnt = __popcll(m);
+    }
   }
-  const int r = block_exclusive_scan(flag, a.block_sums + l * a.sums_stride, lds, wave_off);
+  const int2 off = block_exclusive_scan2(flag, cnt, a.block_sums + l * a.sums_stride, lds, wave_off);
   if (flag) {
+    const int r = off.x;
     a.h[l].rank[s] = r;
     a.bslot[l][r] = s;
-  }
-  if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) a.counts[8 + l] = r + flag;
-}
-
-// voxel rows, pass A: voxels (popcount) per SCAN_BLOCK blocks.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_block_count(PyramidArgs a, int lv0) {
-  __shared__ int lds[SCAN_BLOCK / 64];
-  const int l = lv0 + blockIdx.y;
-  const int n = a.counts[8 + l];
-  if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
-  const int r = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  const int cnt = r < n ? __popcll(a.h[l].mask[a.bslot[l][r]]) : 0;
-  const int tot = block_reduce_sum(cnt, lds);
-  if (threadIdx.x == 0) a.block_sums[l * a.sums_stride + blockIdx.x] = tot;
-}
-
-// pass B: bbase = exclusive scan of the popcounts; compact per-block arrays; voxel count.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_block_base(PyramidArgs a, int lv0) {
-  __shared__ int lds[SCAN_BLOCK / 64];
-  __shared__ int wave_off[SCAN_BLOCK / 64];
-  const int l = lv0 + blockIdx.y;
-  const int n = a.counts[8 + l];
-  const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  if ((int)blockIdx.x >= nwg) return;
-  const int r = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  unsigned long long m = 0;
-  int s = -1;
-  if (r < n) {
-    s = a.bslot[l][r];
-    m = a.h[l].mask[s];
-  }
-  const int cnt = __popcll(m);
-  const int base = block_exclusive_scan(cnt, a.block_sums + l * a.sums_stride, lds, wave_off);
-  if (r < n) {
     a.bkey[l][r] = a.h[l].keys[s];
     a.bmask[l][r] = m;
-    a.bbase[l][r] = base;
+    a.bbase[l][r] = off.y;
     int4 *ch = reinterpret_cast<int4 *>(a.bchild[l] + (size_t)r * 8);
     ch[0] = make_int4(-1, -1, -1, -1);
     ch[1] = make_int4(-1, -1, -1, -1);
   }
-  if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) a.counts[l] = base + cnt;
+  if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) {
+    a.counts[8 + l] = off.x + flag;
+    a.counts[l] = off.y + cnt;
+  }
 }
 
 // point -> voxel row (inverse map of TensorField.sparse / slice, models.py:25,28); also records the
@@ -970,53 +963,92 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 
 // conv0p1s1 (5x5x5x1, 1 -> 8, minkunet.py:55-62) fused with its kernel map.  The input feature is
 // the constant 0.5 (models.py:22; mean of 0.5s, App. A.4), so only the PRESENCE of each of the 125
-// neighbours matters: out[u] = 0.5 * sum_{k present} W[k], k ascending (App. A.8), then BN + ReLU.
-// One thread per voxel; per (dy,dz) the five dx neighbours live in two adjacent blocks whose
-// occupancy masks give the five presence bits at once; no neighbour table is materialised.
+// neighbours matters: out[u] = sum_{k present} 0.5 * W[k], k ascending (App. A.8), then BN + ReLU.
+// One wave = one 16-row tile.  Lane group q fetches the occupancy of the (dy,dz) runs q, q+4, ...
+// (the five dx neighbours of a run live in two adjacent blocks whose masks give five presence bits;
+// all loads of a lane are independent: two round trips in total), the 125-bit presence maps of the
+// four lane groups are OR-ed with two shuffles, and the convolution is 32 MFMAs with
+// A[row][k] = present ? 0.5 : 0 and B[k][n] = W[k][0][n] from LDS.  No neighbour table is materialised.
 __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_out, LevelView L,
                                                       const float *__restrict__ W, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, float in_const,
                                                       float *__restrict__ out, int ldo) {
-  __shared__ float4 w_s[125 * 2];
-  for (int i = threadIdx.x; i < 250; i += blockDim.x) w_s[i] = reinterpret_cast<const float4 *>(W)[i];
+  __shared__ float w_s[128 * 8];
+  for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
   const int n = *n_out;
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    const int r = L.vblock[u];
-    const int bit = L.vbit[u];
-    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
-    const int bo_lo = px < 2 ? -1 : 0;  // the dx run [px-2, px+2] touches blocks bo_lo and bo_lo + 1
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-#pragma unroll 1
-    for (int dz = -2; dz <= 2; ++dz) {
-      const int tz = pz + dz;
+  const int ntiles = (n + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+    const int u = row0 + r;
+    uint32_t bm[4] = {0u, 0u, 0u, 0u};
+#if defined(SPS_ABLATE_C0FETCH)
+    bm[0] = bm[1] = 0x0F0F0F0Fu;
+    if (false) {
+      const int blk = L.vblock[u];
+#else
+    if (u < n) {
+      const int blk = L.vblock[u];
+#endif
+      const int bit = L.vbit[u];
+      const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+      const int bo_lo = px < 2 ? -1 : 0;  // the dx run [px-2, px+2] touches blocks bo_lo and bo_lo + 1
+      const int *adj = L.badj + (size_t)blk * 81;
+      // two batches (4 + 3 runs) keep the kernel at 64 VGPRs = 8 waves per SIMD: one round for ~7k tiles
 #pragma unroll
-      for (int dy = -2; dy <= 2; ++dy) {
-        const int ty = py + dy;
-        const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
-        const int sh = ((tz & 3) << 4) | ((ty & 3) << 2);
-        const int nb0 = L.badj[(size_t)r * 81 + ad0], nb1 = L.badj[(size_t)r * 81 + ad0 + 1];
-        const uint32_t m0 = nb0 >= 0 ? (uint32_t)((L.bmask[nb0] >> sh) & 0xFull) : 0u;
-        const uint32_t m1 = nb1 >= 0 ? (uint32_t)((L.bmask[nb1] >> sh) & 0xFull) : 0u;
-        // window bit i = presence at tx = 4 * bo_lo + i; the run starts at tx = px - 2
-        const uint32_t pres = ((m0 | (m1 << 4)) >> (px - 2 - 4 * bo_lo)) & 0x1Fu;
-        const int k0 = 5 * (dy + 2) + 25 * (dz + 2);
+      for (int half = 0; half < 2; ++half) {
+        int nb0[4], nb1[4];
 #pragma unroll
-        for (int i = 0; i < 5; ++i)
-          if ((pres >> i) & 1u) {
-            const float4 a0 = w_s[(k0 + i) * 2], a1 = w_s[(k0 + i) * 2 + 1];
-            s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
-            s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int c = q + 4 * (4 * half + i);  // run index: dy = c % 5 - 2, dz = c / 5 - 2
+          const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
+          const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
+          const bool on = c < 25;
+          nb0[i] = on ? adj[ad0] : -1;
+          nb1[i] = on ? adj[ad0 + 1] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = q + 4 * (4 * half + i);
+          const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
+          const int sh = ((tz & 3) << 4) | ((ty & 3) << 2);
+          const uint32_t m0 = nb0[i] >= 0 ? (uint32_t)((L.bmask[nb0[i]] >> sh) & 0xFull) : 0u;
+          const uint32_t m1 = nb1[i] >= 0 ? (uint32_t)((L.bmask[nb1[i]] >> sh) & 0xFull) : 0u;
+          // window bit j = presence at tx = 4 * bo_lo + j; the run starts at tx = px - 2
+          const uint32_t pres = c < 25 ? (((m0 | (m1 << 4)) >> (px - 2 - 4 * bo_lo)) & 0x1Fu) : 0u;
+          const int k0 = 5 * c;  // k = 5 c + (dx + 2)
+          const unsigned long long wide = (unsigned long long)pres << (k0 & 31);
+          const int w0 = (k0 >> 5) & 3;
+          bm[0] |= w0 == 0 ? (uint32_t)wide : 0u;
+          bm[1] |= w0 == 1 ? (uint32_t)wide : (w0 == 0 ? (uint32_t)(wide >> 32) : 0u);
+          bm[2] |= w0 == 2 ? (uint32_t)wide : (w0 == 1 ? (uint32_t)(wide >> 32) : 0u);
+          bm[3] |= w0 == 3 ? (uint32_t)wide : (w0 == 2 ? (uint32_t)(wide >> 32) : 0u);
+        }
       }
     }
-    const float v[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    float y[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) y[c] = fmaxf(v[c] * in_const * scale[c] + shift[c], 0.f);
-    float4 *o = reinterpret_cast<float4 *>(out + (size_t)u * ldo);
-    o[0] = make_float4(y[0], y[1], y[2], y[3]);
-    o[1] = make_float4(y[4], y[5], y[6], y[7]);
+    for (int w = 0; w < 4; ++w) {
+      bm[w] |= __shfl_xor(bm[w], 16, 64);
+      bm[w] |= __shfl_xor(bm[w], 32, 64);
+    }
+    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const int k = 4 * g + q;  // (4g + q) >> 5 == g >> 3
+      const float av = ((bm[g >> 3] >> (k & 31)) & 1u) ? in_const : 0.f;
+      const float bv = r < 8 ? w_s[k * 8 + r] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (r < 8) {
+      const float sc = scale[r], sh = shift[r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * sc + sh, 0.f);
+      }
+    }
   }
 }
 
@@ -1563,7 +1595,7 @@ int reserve(sps_ctx *c, int64_t n) {
   }
   c->slab_stride = cap * 64;
   ALLOC(c->slab, float, (size_t)MAX_SPLIT * c->slab_stride);
-  ALLOC(c->block_sums, int, (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
+  ALLOC(c->block_sums, int, 2 * (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
   ALLOC(c->keep, int, cap);
   ALLOC(c->cat8, float, 16 * cap);
   ALLOC(c->b8t, float, 8 * cap);
@@ -1626,7 +1658,7 @@ PyramidArgs pyramid_args(sps_ctx *c) {
   }
   a.counts = c->counts;
   a.block_sums = c->block_sums;
-  a.sums_stride = (int)(c->cap / SCAN_BLOCK + 8);
+  a.sums_stride = (int)(2 * (c->cap / SCAN_BLOCK + 8));
   return a;
 }
 
@@ -1721,7 +1753,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
   a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->cap * 4u);
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
-    hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 256, 2048)), dim3(256), 0, st, a.n_out,
+    hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
                        c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
     return SPS_OK;
   }
@@ -1968,8 +2000,6 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
                      c->err);
   hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
-  hipLaunchKernelGGL(k_block_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0);
-  hipLaunchKernelGGL(k_block_base, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0);
   hipLaunchKernelGGL(k_points_rows, dim3(gp), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
                      L0.vblock, L0.vbit);
   prof_mark(c, "voxelize", st);
@@ -1979,8 +2009,6 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   hipLaunchKernelGGL(k_blocks_to_ancestors, dim3(gb, 4), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(k_first_count, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
   hipLaunchKernelGGL(k_first_rank, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
-  hipLaunchKernelGGL(k_block_count, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1);
-  hipLaunchKernelGGL(k_block_base, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1);
   hipLaunchKernelGGL(k_link_levels, dim3(gb, 4), dim3(256), 0, st, pa);
   (void)gsl;
   prof_mark(c, "pyramid", st);
