@@ -61,7 +61,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=16,
                     help="independent scans in flight per GPU (one HIP stream + native context each); 1 = strictly serial")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
@@ -190,9 +190,15 @@ def main():
             entry["alg_tflops"] = round(pl["flops"] / (acc[name] * 1e-3) / 1e12, 2) if acc[name] > 0 else None
         stages.append(entry)
     dom = max((s for s in stages if s["stage"] in work["per_layer"]), key=lambda s: s["ms"])
+    # HBM bytes per scan from the committed PMC passes of this build (tools/traffic_pmc.py), if present
+    traffic, traffic_note = None, "not measured for this build"
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        tj = json.load(open(tp))
+        traffic, traffic_note = tj["hbm_bytes_per_scan"], tj["method"]
     roof = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / roofline.HBM_PEAK_GBS, 5), "traffic": None,
+        "frac": round(achieved / roofline.HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
         "kernel": "whole per-scan path (all launches of one forward + metric sums); "
                   f"{S} independent scans in flight on {S} HIP streams" if S > 1 else
                   "whole per-scan path (all launches of one forward + metric sums), strictly serial",

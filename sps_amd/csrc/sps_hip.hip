@@ -480,21 +480,25 @@ __global__ void k_link_levels(PyramidArgs a) {
 // adjacency of blocks (blockIdx.y = level): badj[r][a] = rank of the block at offset (dbx,dby,dbz,dt)
 // in {-1,0,1}^4, a = (dbx+1) + 3(dby+1) + 9(dbz+1) + 27(dt+1), or -1.  The only hash probes of the
 // kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
-__global__ void k_block_adj(PyramidArgs a) {
-  const int level = blockIdx.y;
-  const int total = a.counts[8 + level] * 81;  // < 2^31: blocks <= points < 2^30 / 81 is enforced by reserve()
+__global__ void k_block_adj(PyramidArgs a, int c1, int c2, int c3, int c4, int c5) {
+  // workgroup -> (level, chunk): chunk offsets 0, c1, c2, c3, c4, c5 (expected sizes, grid-stride beyond)
+  const int bx = (int)blockIdx.x;
+  const int level = bx < c1 ? 0 : bx < c2 ? 1 : bx < c3 ? 2 : bx < c4 ? 3 : 4;
+  const int lo = level == 0 ? 0 : level == 1 ? c1 : level == 2 ? c2 : level == 3 ? c3 : c4;
+  const int hi = level == 0 ? c1 : level == 1 ? c2 : level == 2 ? c3 : level == 3 ? c4 : c5;
+  const int total = a.counts[8 + level] * 81;  // < 2^31: blocks <= points <= 2^23
   const int lim = 1 << (16 - level);  // block coordinates of this level live in [0, lim)
   const BHash h = a.h[level];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = (bx - lo) * blockDim.x + threadIdx.x; i < total; i += (hi - lo) * blockDim.x) {
     const int r = i / 81, ad = i - r * 81;
     const uint64_t key = a.bkey[level][r];
-    const int bx = (int)(key & 0x3FFFF) + (ad % 3 - 1), by = (int)((key >> 18) & 0x3FFFF) + ((ad / 3) % 3 - 1),
+    const int bxx = (int)(key & 0x3FFFF) + (ad % 3 - 1), by = (int)((key >> 18) & 0x3FFFF) + ((ad / 3) % 3 - 1),
               bz = (int)((key >> 36) & 0x3FFFF) + ((ad / 9) % 3 - 1), tt = (int)((key >> 54) & 0x1F) + (ad / 27 - 1);
     int res = -1;
     if (ad == 40) {
       res = r;
-    } else if (bx >= 0 && bx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32) {
-      const int s = bhash_find(h, bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bx, (uint32_t)by, (uint32_t)bz));
+    } else if (bxx >= 0 && bxx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32) {
+      const int s = bhash_find(h, bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bxx, (uint32_t)by, (uint32_t)bz));
       if (s >= 0) res = h.rank[s];
     }
     a.badj[level][i] = res;
@@ -2014,7 +2018,11 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   prof_mark(c, "pyramid", st);
   // ---- kernel maps
   // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
-  hipLaunchKernelGGL(k_block_adj, dim3(grid_for((cap >> 2) * 81, 256, 16384), NLV), dim3(256), 0, st, pa);
+  {
+    int co[NLV + 1] = {0};
+    for (int l = 0; l < NLV; ++l) co[l + 1] = co[l] + grid_for(((cap >> 3) >> (2 * l)) * 81, 256, 8192);
+    hipLaunchKernelGGL(k_block_adj, dim3(co[NLV]), dim3(256), 0, st, pa, co[1], co[2], co[3], co[4], co[5]);
+  }
   MapsArgs ma{};
   int off = 0;
   for (int l = 0; l < NLV; ++l) {

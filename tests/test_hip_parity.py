@@ -359,3 +359,33 @@ def test_predict_cli_synthetic():
     assert "########## Inference Metrics ##########" in out
     for name in ("Loss", "R2", "dIoU", "Precision", "Recall", "F1"):
         assert any(line.startswith(name + " .") for line in out.splitlines()), name
+
+
+def test_streaming_filter_pipeline(net, params):
+    """sps_node.callback minus ROS: pose transform -> submap -> infer -> keep score <= eps."""
+    from sps_amd.pipeline import StableFilter
+    import sps.datasets.util as util
+    rng = np.random.default_rng(8)
+    map_pts = synthetic.build_map(n_azimuth=400, n_beams=32)
+    scan_world = synthetic.lidar_scan(77, x_offset=1.0, n_azimuth=400, n_beams=32)[:, :3].astype(np.float64)
+    ang = 0.4
+    pose = np.array([[np.cos(ang), -np.sin(ang), 0, 1.0], [np.sin(ang), np.cos(ang), 0, -0.5], [0, 0, 1, 0.0], [0, 0, 0, 1.0]])
+    sensor = util.inverse_transform_point_cloud(scan_world, pose)
+    f = StableFilter(net, torch.from_numpy(map_pts), voxel_size=VS, epsilon=EPS)
+    res = f(sensor, pose)
+    # oracle: same stages on the CPU
+    world = util.transform_point_cloud(sensor, pose).astype(np.float32)
+    sub, n_sv = O.prune(O.to_coords(map_pts[:, :3], VS), O.to_coords(world, VS), VS)
+    assert (res.n_scan_voxels, res.n_submap_voxels) == (n_sv, len(sub))
+    batch = synthetic.assemble(np.c_[world, np.zeros(len(world))].astype(np.float32), sub)
+    ref, _ = O.sps_forward(params, batch[:, :5], VS)
+    n = len(world)
+    np.testing.assert_allclose(res.scores.cpu().numpy(), ref[:n], rtol=0, atol=1e-4)
+    keep = ref[:n] <= np.float32(EPS)
+    band = np.abs(ref[:n] - np.float32(EPS)) > 1e-5
+    got_keep = (res.scores.cpu().numpy() <= np.float32(EPS))
+    np.testing.assert_array_equal(got_keep[band], keep[band])
+    assert res.filtered.shape == (int(got_keep.sum()), 3)
+    np.testing.assert_allclose(res.filtered.cpu().numpy(), sensor[got_keep].astype(np.float32), rtol=0, atol=0)
+    assert res.t_total >= res.t_infer > 0 and res.t_prune > 0
+    util._MAP_CACHE.clear()
