@@ -63,6 +63,8 @@ def main():
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
     ap.add_argument("--streams", type=int, default=16,
                     help="independent scans in flight per GPU (one HIP stream + native context each); 1 = strictly serial")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
+                    "exercising the multi-rank control flow on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
@@ -75,13 +77,18 @@ def main():
             raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
                              f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+    if args.backend != "nccl":
+        local = local % max(torch.cuda.device_count(), 1)      # debug: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from sps_amd import roofline, synthetic
     from sps_amd.models.models import SPSNet, get_context, metrics_from_sums

@@ -537,10 +537,12 @@ struct LevelView {
 
 // bit k of tile (u >> 4): "some row of the 16-row tile has a neighbour through offset k".
 // blockDim.x and the grid stride are multiples of 64, so a 16-lane segment of a wave is one tile.
-__device__ inline void tile_mask_or(uint32_t *tmask, int u, int k, bool present) {
+__device__ inline bool tile_mask_or(uint32_t *tmask, int u, int k, bool present) {
   const unsigned long long bal = __ballot(present);
   const int lane = threadIdx.x & 63;
-  if ((lane & 15) == 0 && ((bal >> lane) & 0xFFFFull)) atomicOr(&tmask[(size_t)(u >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+  const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile is present
+  if ((lane & 15) == 0 && any) atomicOr(&tmask[(size_t)(u >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+  return any;
 }
 
 // Per-level arguments of the flattened multi-level map kernels: workgroup blockIdx.x belongs to the
@@ -591,8 +593,8 @@ __device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int
     int row = -1;
     if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
     const int k = k0 + dx + R;
-    nbr[(size_t)k * ldn + u] = row;
-    tile_mask_or(tmask, u, k, row >= 0);
+    // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
+    if (tile_mask_or(tmask, u, k, row >= 0)) nbr[(size_t)k * ldn + u] = row;
   }
 }
 
@@ -673,12 +675,13 @@ __global__ __launch_bounds__(256) void k_build_stride_maps(MapsArgs a) {
 }
 
 __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, const int *__restrict__ n_ptr,
-                              unsigned long long *__restrict__ pairs) {
+                              const uint32_t *__restrict__ tmask, unsigned long long *__restrict__ pairs) {
   const int n = *n_ptr;
   const int k = blockIdx.y;
   int c = 0;
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
-    c += nbr[(size_t)k * ldn + u] >= 0;
+    if ((tmask[(size_t)(u >> 4) * 4 + (k >> 5)] >> (k & 31)) & 1u)  // entries of absent (tile, k) are never written
+      c += nbr[(size_t)k * ldn + u] >= 0;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pairs[k], (unsigned long long)c);
 }
@@ -1085,47 +1088,61 @@ __global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__r
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_metrics(const float *__restrict__ scores, const float *__restrict__ batch, int64_t ld, int n,
                           float eps, int n_batches, double *__restrict__ acc) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // Few workgroups, each thread accumulates its rows in registers; a thread flushes early only when
+  // the batch index of its rows changes (rows are grouped by b), so the 8 accumulators of a batch
+  // index see ~one atomic per workgroup instead of one per 256 rows.
+  __shared__ double red[8][4];
+  __shared__ int bsh[4];
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int b = -1;
-  if (p < n) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
     const float *row = batch + (size_t)p * ld;
-    if (row[4] == 1.0f) {
-      const int bi = (int)row[0];
-      if (bi >= 0 && bi < n_batches) {
-        b = bi;
-        const float s = scores[p], g = row[5];
-        const int pred = s < eps ? 0 : 1, gt = g < eps ? 0 : 1;
-        const double d = (double)s - (double)g;
-        v[0] = 1;
-        v[1] = (gt == 1 && pred == 1);
-        v[2] = (gt == 0 && pred == 1);
-        v[3] = (gt == 1 && pred == 0);
-        v[4] = (gt == 0 && pred == 0);
-        v[5] = d * d;
-        v[6] = g;
-        v[7] = (double)g * (double)g;
+    if (row[4] != 1.0f) continue;  // scan rows only (t == 1)
+    const int bi = (int)row[0];
+    if (bi < 0 || bi >= n_batches) continue;
+    if (bi != b) {
+      if (b >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (v[j] != 0.0) atomicAdd(&acc[b * 8 + j], v[j]);
+          v[j] = 0.0;
+        }
       }
+      b = bi;
+    }
+    const float s = scores[p], g = row[5];
+    const int pred = s < eps ? 0 : 1, gt = g < eps ? 0 : 1;
+    const double d = (double)s - (double)g;
+    v[0] += 1;
+    v[1] += (gt == 1 && pred == 1);
+    v[2] += (gt == 0 && pred == 1);
+    v[3] += (gt == 1 && pred == 0);
+    v[4] += (gt == 0 && pred == 0);
+    v[5] += d * d;
+    v[6] += g;
+    v[7] += (double)g * (double)g;
+  }
+  // workgroup reduction when all its threads ended on the same batch index (the common case)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bmax = b, bmin = b < 0 ? 0x7fffffff : b;
+  for (int o = 32; o > 0; o >>= 1) {
+    bmax = max(bmax, __shfl_xor(bmax, o, 64));
+    bmin = min(bmin, __shfl_xor(bmin, o, 64));
+  }
+  if (lane == 0) bsh[wave] = (bmax < 0) ? -1 : (bmin == bmax ? bmax : -2);
+  __syncthreads();
+  int wb = -1;
+  bool uniform = true;
+  for (int i = 0; i < 4; ++i) {
+    const int x = bsh[i];
+    if (x == -2) uniform = false;
+    else if (x >= 0) {
+      if (wb >= 0 && wb != x) uniform = false;
+      wb = x;
     }
   }
-  // block-level reduction when every contributing lane of the block shares one batch index (the
-  // common case: rows are grouped by b); one atomic per block and accumulator.
-  __shared__ double red[8][4];
-  __shared__ int bmin_s, bmax_s;
-  if (threadIdx.x == 0) {
-    bmin_s = 0x7fffffff;
-    bmax_s = -1;
-  }
-  __syncthreads();
-  if (b >= 0) {
-    atomicMin(&bmin_s, b);
-    atomicMax(&bmax_s, b);
-  }
-  __syncthreads();
-  const int bmin = bmin_s, bmax = bmax_s;
-  if (bmax < 0) return;  // block-uniform
-  if (bmin == bmax) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (wb < 0 && uniform) return;
+  if (uniform) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       double x = v[j];
@@ -1135,7 +1152,7 @@ __global__ __launch_bounds__(256) void k_metrics(const float *__restrict__ score
     __syncthreads();
     if (threadIdx.x < 8) {
       const double x = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-      if (x != 0.0) atomicAdd(&acc[bmax * 8 + threadIdx.x], x);
+      if (x != 0.0) atomicAdd(&acc[wb * 8 + threadIdx.x], x);
     }
   } else if (b >= 0) {
 #pragma unroll
@@ -2135,7 +2152,7 @@ int sps_metrics(sps_ctx *c, const float *scores, const float *batch, int64_t ld,
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(c->macc, 0, (size_t)n_batches * 8 * sizeof(double), st));
   if (n > 0)
-    hipLaunchKernelGGL(k_metrics, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
                        n_batches, c->macc);
   HIP_TRY(hipMemcpyAsync(out_host, c->macc, (size_t)n_batches * 8 * sizeof(double), hipMemcpyDeviceToHost, st));
   int e = 0;
@@ -2230,7 +2247,7 @@ int sps_metrics_dev(sps_ctx *c, const float *scores, const float *batch, int64_t
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n_batches * 8 * sizeof(double), st));
   if (n > 0)
-    hipLaunchKernelGGL(k_metrics, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
                        n_batches, out_dev);
   HIP_TRY(hipGetLastError());
   return SPS_OK;
@@ -2305,7 +2322,7 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
                        c->lv[0].view(), c->nbr5, c->cap, c->tm5);
   HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
   hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, c->cap,
-                     c->counts + level, c->pairs);
+                     c->counts + level, which == 5 ? c->tm5 : c->lv[which].tm3, c->pairs);
   unsigned long long h[128];
   HIP_TRY(hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost));
   for (int k = 0; k < K; ++k) pairs_host[k] = (int64_t)h[k];
