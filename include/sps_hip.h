@@ -146,6 +146,9 @@ int sps_get_map_pairs(sps_ctx *ctx, int which, int64_t *pairs_host);
 /* Present-offset masks of the 16-row output tiles of a kernel map (which as above): uint32
  * [n_tiles][4]; bit k set = some row of the tile has a neighbour through offset k. */
 int sps_get_tile_masks(sps_ctx *ctx, int which, uint32_t *masks_dev, int64_t *n_tiles);
+/* The 3x3x3x3 neighbour table of level `which` (0..4), int32 [81][V] compact; entries of (tile, k)
+ * pairs whose tile-mask bit is clear are unspecified (never written, never read by the convolution). */
+int sps_get_nbr(sps_ctx *ctx, int which, int32_t *nbr_dev);
 /* Per-voxel logits of the last forward, float32 [V_0]. */
 int sps_get_logits(sps_ctx *ctx, float *logits_dev);
 /* Named intermediate feature maps: "out_p1","block1".."block8"; copies [V,C] row-major

@@ -54,6 +54,7 @@ def _load() -> C.CDLL:
         "sps_get_parent": (i32, [vp, i32, vp]),
         "sps_get_map_pairs": (i32, [vp, i32, C.POINTER(i64)]),
         "sps_get_tile_masks": (i32, [vp, i32, vp, C.POINTER(i64)]),
+        "sps_get_nbr": (i32, [vp, i32, vp]),
         "sps_get_logits": (i32, [vp, vp]),
         "sps_get_feature": (i32, [vp, C.c_char_p, vp, C.POINTER(i64), C.POINTER(i64)]),
     }
@@ -70,7 +71,7 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_forward", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_level_counts", "sps_get_voxels",
-           "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_logits", "sps_get_feature"]
+           "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_logits", "sps_get_feature"]
 
 
 def check(rc: int) -> None:
