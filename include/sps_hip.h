@@ -121,6 +121,27 @@ int sps_submap_voxel(sps_ctx *ctx, const float *scan_xyz_dev, int64_t ld, int64_
 int sps_submap_voxel_ijk(sps_ctx *ctx, const int32_t *scan_ijk_dev, int64_t ld, int64_t n, float ds,
                          float *out_xyz_dev, int64_t *n_sub, int64_t *n_scan_vox, void *stream);
 
+/* ---- variant-A submap (offline path) ----------------------------------------------------
+ * Replaces BacchusDataset.select_closest_points (reference src/sps/datasets/blt_dataset.py:258-271:
+ * scipy cKDTree.query_ball_tree(map_tree, r = VOXEL_SIZE)): for every scan point the indices of the
+ * map points within Euclidean distance r (closed ball, float64), one hit list per scan point,
+ * concatenated in scan-point order with duplicates kept; inside a list the hits are ordered by
+ * neighbour cell ((dx+1) + 3(dy+1) + 9(dz+1)), ascending map index inside a cell (scipy's in-list
+ * order is the tree's traversal order, i.e. unspecified).
+ * The map is binned by the caller into cells of size cell_size >= r: cell_keys (u64, see
+ * sps_amd/datasets/blt_dataset.py), cell_start [n_cells+1], cell_pts [m] (map indices grouped by cell),
+ * map_xyz float64 [m,3] compact.  The ctx keeps device copies.  Synchronises. */
+int sps_radius_grid_upload(sps_ctx *ctx, const uint64_t *cell_keys_dev, const int32_t *cell_start_dev,
+                           const int32_t *cell_pts_dev, const double *map_xyz_dev, int64_t n_cells, int64_t m,
+                           double cell_size, double r, void *stream);
+/* counts_dev[i*27 + c] = number of hits of scan point i in its neighbour cell c (float64 rows xyz...,
+ * row stride ld); counts_dev holds 27*n ints. */
+int sps_radius_count(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64_t n, int32_t *counts_dev, void *stream);
+/* Writes the hits of (point i, cell c) at out_idx_dev[offsets_dev[i*27 + c] ...] (offsets = exclusive prefix
+ * sum of the 27*n counts, computed by the caller), so a point's list is contiguous. */
+int sps_radius_fill(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64_t n, const int64_t *offsets_dev,
+                    int64_t *out_idx_dev, void *stream);
+
 /* ---- per-stage timing (hipEvents on the caller's stream; for bench.py / DESIGN.md) ------
  * With profiling on, sps_forward records one event after every stage ("reset", "voxelize",
  * "pyramid", "maps", one per convolution by state_dict name, "slice_sigmoid").  After a forward,

@@ -48,6 +48,9 @@ def _load() -> C.CDLL:
         "sps_map_upload_voxels": (i32, [vp, vp, i64, i64, vp]),
         "sps_submap_voxel": (i32, [vp, vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp]),
         "sps_submap_voxel_ijk": (i32, [vp, vp, i64, i64, f32, vp, C.POINTER(i64), C.POINTER(i64), vp]),
+        "sps_radius_grid_upload": (i32, [vp, vp, vp, vp, vp, i64, i64, C.c_double, C.c_double, vp]),
+        "sps_radius_count": (i32, [vp, vp, i64, i64, vp, vp]),
+        "sps_radius_fill": (i32, [vp, vp, i64, i64, vp, vp, vp]),
         "sps_level_counts": (i32, [vp, C.POINTER(i64)]),
         "sps_get_voxels": (i32, [vp, i32, vp]),
         "sps_get_inverse": (i32, [vp, vp]),
@@ -70,7 +73,8 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
            "sps_forward", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
-           "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_level_counts", "sps_get_voxels",
+           "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_radius_grid_upload", "sps_radius_count",
+           "sps_radius_fill", "sps_level_counts", "sps_get_voxels",
            "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_logits", "sps_get_feature"]
 
 

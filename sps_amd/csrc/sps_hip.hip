@@ -1490,6 +1490,69 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_keep_write(const int *__restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// variant-A submap (blt_dataset.py:258-271): map points within Euclidean radius r of a scan point.
+// The map is binned once into a uniform grid of cell size >= r (sorted by cell, ascending point index
+// inside a cell); a query visits the 27 cells around the scan point and applies the exact float64 test
+// dx*dx + dy*dy + dz*dz <= r*r (no FMA contraction: same arithmetic as scipy's cKDTree leaf test).
+// ------------------------------------------------------------------------------------------
+struct RadiusGrid {
+  HashTable h;             // cell key -> cell id (rank)
+  const int *cell_start;   // [C + 1]
+  const int *cell_pts;     // [M] map point indices, grouped by cell
+  const double *xyz;       // [M, 3] map points (compact)
+  double inv_cell, r2;
+};
+
+__device__ inline bool radius_cell(double v, double inv_cell, long long &c) {
+  const double f = floor(v * inv_cell);
+  if (!(f >= -1048575.0 && f <= 1048575.0)) return false;
+  c = (long long)f;
+  return true;
+}
+__device__ inline uint64_t radius_key(long long cx, long long cy, long long cz) {
+  return ((uint64_t)(cz + 1048576) << 42) | ((uint64_t)(cy + 1048576) << 21) | (uint64_t)(cx + 1048576);
+}
+
+__global__ void k_radius_cells_insert(const unsigned long long *__restrict__ cell_keys, int ncell, HashTable h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncell) return;
+  const int s = hash_insert(h, cell_keys[i]);
+  h.rank[s] = i;
+}
+
+// One thread per (scan point i, neighbour cell c in 0..26; c = (dx+1) + 3(dy+1) + 9(dz+1)).
+// MODE 0: counts[i*27 + c] = hits of point i in that cell.  MODE 1: write them at offsets[i*27 + c].
+// A point's list is therefore ordered by cell, ascending map index inside a cell.
+template <int MODE>
+__global__ void k_radius_query(const double *__restrict__ scan, int64_t ld, int n, RadiusGrid g,
+                               int *__restrict__ counts, const int64_t *__restrict__ offsets,
+                               int64_t *__restrict__ out) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (int64_t)n * 27) return;
+  const int i = (int)(tid / 27), c27 = (int)(tid - (int64_t)i * 27);
+  const double px = scan[(size_t)i * ld], py = scan[(size_t)i * ld + 1], pz = scan[(size_t)i * ld + 2];
+  long long cx, cy, cz;
+  int cnt = 0;
+  int64_t *dst = MODE == 1 ? out + offsets[tid] : nullptr;
+  if (radius_cell(px, g.inv_cell, cx) && radius_cell(py, g.inv_cell, cy) && radius_cell(pz, g.inv_cell, cz)) {
+    const int s = hash_find_slot(g.h, radius_key(cx + (c27 % 3 - 1), cy + ((c27 / 3) % 3 - 1), cz + (c27 / 9 - 1)));
+    if (s >= 0) {
+      const int c = g.h.rank[s];
+      for (int t = g.cell_start[c]; t < g.cell_start[c + 1]; ++t) {
+        const int j = g.cell_pts[t];
+        const double ex = px - g.xyz[(size_t)j * 3], ey = py - g.xyz[(size_t)j * 3 + 1], ez = pz - g.xyz[(size_t)j * 3 + 2];
+        const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
+        if (d2 <= g.r2) {
+          if (MODE == 1) dst[cnt] = j;
+          ++cnt;
+        }
+      }
+    }
+  }
+  if (MODE == 0) counts[tid] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
 // small utility kernels
 // ------------------------------------------------------------------------------------------
 __global__ void k_rows_to_coords(const int *__restrict__ vblock, const unsigned char *__restrict__ vbit,
@@ -1717,6 +1780,9 @@ struct sps_ctx {
   std::vector<hipEvent_t> prof_ev;
   std::vector<std::string> prof_names;
   size_t prof_n = 0;
+  // variant-A radius grid (device copies owned by the ctx)
+  RadiusGrid rg{};
+  std::vector<void *> rg_allocs;
   // map hash (variant-B submap)
   HashTable map{};
   int64_t map_cap = 0;
@@ -2138,6 +2204,7 @@ int sps_ctx_destroy(sps_ctx *c) {
   (void)hipFree(c->ss);
   (void)hipFree(c->wu);
   if (c->map_keys_alloc) (void)hipFree(c->map_keys_alloc);
+  for (void *p : c->rg_allocs) (void)hipFree(p);
   delete c;
   return SPS_OK;
 }
@@ -2516,6 +2583,77 @@ int sps_submap_voxel(sps_ctx *c, const float *scan_xyz, int64_t ld, int64_t n, f
 int sps_submap_voxel_ijk(sps_ctx *c, const int32_t *scan_ijk, int64_t ld, int64_t n, float ds, float *out_xyz,
                          int64_t *n_sub, int64_t *n_scan_vox, void *stream) {
   return submap_impl(c, scan_ijk, true, ld, n, ds, out_xyz, n_sub, n_scan_vox, stream);
+}
+
+int sps_radius_grid_upload(sps_ctx *c, const uint64_t *cell_keys_dev, const int32_t *cell_start_dev,
+                           const int32_t *cell_pts_dev, const double *map_xyz_dev, int64_t n_cells, int64_t m,
+                           double cell_size, double r, void *stream) {
+  if (!c || n_cells < 0 || m < 0 || !(r > 0.0) || !(cell_size >= r)) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (m > 0 && (!cell_keys_dev || !cell_start_dev || !cell_pts_dev || !map_xyz_dev)) return fail(SPS_ERR_INVALID, "null argument");
+  if (m >= (1ll << 31) || n_cells >= (1ll << 30)) return fail(SPS_ERR_INVALID, "map too large");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  HIP_TRY(hipDeviceSynchronize());
+  for (void *p : c->rg_allocs) (void)hipFree(p);
+  c->rg_allocs.clear();
+  c->rg = RadiusGrid{};
+  auto alloc = [&](void **p, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(p, bytes ? bytes : 16);
+    if (e == hipSuccess) c->rg_allocs.push_back(*p);
+    return e;
+  };
+  const int64_t hcap = next_pow2(2 * (n_cells < 512 ? 512 : n_cells));
+  void *keys = nullptr, *rank = nullptr, *start = nullptr, *pts = nullptr, *xyz = nullptr;
+  if (alloc(&keys, (size_t)hcap * 8) != hipSuccess || alloc(&rank, (size_t)hcap * 4) != hipSuccess ||
+      alloc(&start, (size_t)(n_cells + 1) * 4) != hipSuccess || alloc(&pts, (size_t)m * 4) != hipSuccess ||
+      alloc(&xyz, (size_t)m * 24) != hipSuccess)
+    return fail(SPS_ERR_NOMEM, "hipMalloc for the radius grid failed");
+  HIP_TRY(hipMemsetAsync(keys, 0xFF, (size_t)hcap * 8, st));
+  if (m > 0) {
+    HIP_TRY(hipMemcpyAsync(start, cell_start_dev, (size_t)(n_cells + 1) * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(pts, cell_pts_dev, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(xyz, map_xyz_dev, (size_t)m * 24, hipMemcpyDeviceToDevice, st));
+  }
+  c->rg.h.keys = (uint64_t *)keys;
+  c->rg.h.first = nullptr;
+  c->rg.h.rank = (int *)rank;
+  c->rg.h.mask = (uint32_t)(hcap - 1);
+  c->rg.cell_start = (const int *)start;
+  c->rg.cell_pts = (const int *)pts;
+  c->rg.xyz = (const double *)xyz;
+  c->rg.inv_cell = 1.0 / cell_size;
+  c->rg.r2 = r * r;
+  if (n_cells > 0)
+    hipLaunchKernelGGL(k_radius_cells_insert, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, st,
+                       (const unsigned long long *)cell_keys_dev, (int)n_cells, c->rg.h);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(st));
+  return SPS_OK;
+}
+
+int sps_radius_count(sps_ctx *c, const double *scan_xyz_dev, int64_t ld, int64_t n, int32_t *counts_dev, void *stream) {
+  if (!c || n < 0 || ld < 3 || (n > 0 && (!scan_xyz_dev || !counts_dev))) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!c->rg.h.keys) return fail(SPS_ERR_INVALID, "sps_radius_grid_upload has not been called");
+  if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points");
+  HIP_TRY(hipSetDevice(c->device));
+  if (n > 0)
+    hipLaunchKernelGGL(k_radius_query<0>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       scan_xyz_dev, ld, (int)n, c->rg, counts_dev, nullptr, nullptr);
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_radius_fill(sps_ctx *c, const double *scan_xyz_dev, int64_t ld, int64_t n, const int64_t *offsets_dev,
+                    int64_t *out_idx_dev, void *stream) {
+  if (!c || n < 0 || ld < 3 || (n > 0 && (!scan_xyz_dev || !offsets_dev || !out_idx_dev))) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!c->rg.h.keys) return fail(SPS_ERR_INVALID, "sps_radius_grid_upload has not been called");
+  if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points");
+  HIP_TRY(hipSetDevice(c->device));
+  if (n > 0)
+    hipLaunchKernelGGL(k_radius_query<1>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       scan_xyz_dev, ld, (int)n, c->rg, nullptr, offsets_dev, out_idx_dev);
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
 }
 
 // ---- introspection ---------------------------------------------------------------------------

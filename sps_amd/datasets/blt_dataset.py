@@ -133,3 +133,65 @@ class BacchusDataset(Dataset):
         if len(hits) == 0:
             return np.zeros(0, dtype=int)
         return np.concatenate([np.asarray(h, dtype=np.int64) for h in hits]).astype(int)
+
+
+class DeviceRadiusSubmap:
+    """select_closest_points (:258-271) on the MI355X: a uniform grid over the map (cell size just above
+    r), exact float64 radius test over the 27 neighbour cells (C ABI: sps_radius_*).  Returns, like the
+    reference, the concatenation over scan points of the indices of the map points within r, duplicates
+    kept; inside one scan point's list the hits are ordered by neighbour cell, ascending map index inside a
+    cell (scipy's order there is the KD-tree's traversal order, i.e. unspecified)."""
+
+    def __init__(self, map_xyz, radius: float, device="cuda"):
+        from ..models import models
+        self.radius = float(radius)
+        self.device = torch.device(device)
+        xyz = torch.as_tensor(np.ascontiguousarray(np.asarray(map_xyz)[:, :3], dtype=np.float64)).to(self.device)
+        cell = self.radius * (1.0 + 1e-7)                   # >= r, so every hit lies in the 27 cells around the query
+        c = torch.floor(xyz / cell).to(torch.int64)
+        assert int(c.abs().max()) < (1 << 20) - 1, "map extent exceeds the radius grid"
+        keys = ((c[:, 2] + (1 << 20)) << 42) | ((c[:, 1] + (1 << 20)) << 21) | (c[:, 0] + (1 << 20))
+        skeys, order = torch.sort(keys, stable=True)        # grouped by cell, ascending map index inside a cell
+        ukeys, counts = torch.unique_consecutive(skeys, return_counts=True)
+        start = torch.zeros(len(ukeys) + 1, dtype=torch.int32, device=self.device)
+        start[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        pts = order.to(torch.int32).contiguous()
+        with torch.cuda.device(self.device):
+            self.stream = torch.cuda.current_stream().cuda_stream
+            self.ctx = models.get_context(self.device.index or 0, self.stream)
+            from .. import _native
+            _native.check(_native.lib.sps_radius_grid_upload(
+                self.ctx.handle, ukeys.contiguous().data_ptr(), start.data_ptr(), pts.data_ptr(), xyz.data_ptr(),
+                len(ukeys), len(xyz), cell, self.radius, self.stream))
+
+    def query(self, scan_xyz):
+        """scan_xyz [n, >=3] -> (indices int64 [total], counts int32 [n]) as device tensors."""
+        from .. import _native
+        s = torch.as_tensor(np.ascontiguousarray(np.asarray(scan_xyz)[:, :3], dtype=np.float64)
+                            if not torch.is_tensor(scan_xyz) else scan_xyz[:, :3].to(torch.float64).contiguous())
+        s = s.to(self.device)
+        n = len(s)
+        counts27 = torch.empty(n * 27, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream().cuda_stream
+            _native.check(_native.lib.sps_radius_count(self.ctx.handle, s.data_ptr(), 3, n, counts27.data_ptr(), st))
+            offsets = torch.zeros(n * 27 + 1, dtype=torch.int64, device=self.device)
+            offsets[1:] = torch.cumsum(counts27, 0)
+            total = int(offsets[-1].item())
+            out = torch.empty(total, dtype=torch.int64, device=self.device)
+            _native.check(_native.lib.sps_radius_fill(self.ctx.handle, s.data_ptr(), 3, n, offsets.data_ptr(),
+                                                      out.data_ptr(), st))
+        return out, counts27.view(n, 27).sum(1).to(torch.int32)
+
+
+def device_item(dataset: BacchusDataset, idx: int, submap: DeviceRadiusSubmap) -> torch.Tensor:
+    """BacchusDataset.__getitem__ (:209-244) with the submap selected on the device: float32 [n, 5] on the GPU
+    = [scan (x,y,z,t=1,label); submap (x,y,z,t=0,label=1)]."""
+    scan = dataset.scans[idx]
+    dev = submap.device
+    sub_idx, _ = submap.query(scan[:, :3])
+    s = torch.as_tensor(np.asarray(scan[:, :4])).to(dev)
+    scan_rows = torch.cat([s[:, :3].to(torch.float32), torch.ones(len(s), 1, device=dev), s[:, 3:4].to(torch.float32)], 1)
+    m = torch.as_tensor(np.asarray(dataset.map[:, :3])).to(dev)[sub_idx].to(torch.float32)
+    sub_rows = torch.cat([m, torch.zeros(len(m), 1, device=dev), torch.ones(len(m), 1, device=dev)], 1)
+    return torch.cat([scan_rows, sub_rows], 0)

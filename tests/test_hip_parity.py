@@ -389,3 +389,38 @@ def test_streaming_filter_pipeline(net, params):
     np.testing.assert_allclose(res.filtered.cpu().numpy(), sensor[got_keep].astype(np.float32), rtol=0, atol=0)
     assert res.t_total >= res.t_infer > 0 and res.t_prune > 0
     util._MAP_CACHE.clear()
+
+
+def test_variant_a_radius_submap_matches_scipy():
+    """select_closest_points on the device vs scipy cKDTree.query_ball_tree (blt_dataset.py:258-271):
+    per scan point the same hit multiset; the assembled item equals the reference-layout item."""
+    from scipy.spatial import cKDTree
+    import sps.datasets.blt_dataset as blt
+    rng = np.random.default_rng(12)
+    pc_map = np.concatenate([rng.uniform(-5, 5, (40000, 3)), rng.uniform(0, 1, (40000, 1))], 1)      # float64
+    idx = rng.choice(len(pc_map), 3000, replace=False)
+    scan = np.concatenate([pc_map[idx, :3] + rng.normal(0, 0.05, (3000, 3)), rng.uniform(0, 1, (3000, 1))], 1)
+    scan[:50, :3] = pc_map[idx[:50], :3]                      # exact coincidences
+    scan[50:60, :3] += 100.0                                  # far away: empty hit lists
+    r = 0.1
+    want = cKDTree(scan[:, :3]).query_ball_tree(cKDTree(pc_map[:, :3]), r)
+    sub = blt.DeviceRadiusSubmap(pc_map[:, :3], r)
+    got, counts = sub.query(scan[:, :3])
+    got, counts = got.cpu().numpy(), counts.cpu().numpy()
+    assert counts.tolist() == [len(w) for w in want]
+    off = np.concatenate([[0], np.cumsum(counts)])
+    for i, w in enumerate(want):
+        assert sorted(got[off[i]:off[i + 1]].tolist()) == sorted(w), i
+    # assembled item == reference layout (rows of a scan point's list sorted by map index)
+    cfg = {"TRAIN": {"AUGMENTATION": False}, "MODEL": {"VOXEL_SIZE": r}}
+    ds = blt.BacchusDataset(cfg, [scan], pc_map)
+    item = blt.device_item(ds, 0, sub).cpu().numpy()
+    assert item.shape == (len(scan) + len(got), 5)
+    np.testing.assert_array_equal(item[:len(scan), :3], scan[:, :3].astype(np.float32))
+    np.testing.assert_array_equal(item[len(scan):, :3], pc_map[got, :3].astype(np.float32))
+    assert (item[:len(scan), 3] == 1).all() and (item[len(scan):, 3] == 0).all() and (item[len(scan):, 4] == 1).all()
+    # same voxel set as the reference item -> same scores
+    ref_item = ds[0].numpy()
+    a = np.unique(O.quantize(np.pad(item[:, :4], ((0, 0), (1, 0))), r), axis=0)
+    b = np.unique(O.quantize(np.pad(ref_item[:, :4], ((0, 0), (1, 0))), r), axis=0)
+    np.testing.assert_array_equal(a, b)
