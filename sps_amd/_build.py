@@ -9,8 +9,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(CSRC, "libsps_hip.so")
-SOURCES = [os.path.join(CSRC, "sps_hip.hip")]
-HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sps_hip.h")]
+SOURCES = [os.path.join(CSRC, "sps_hip.hip")]          # one translation unit; the *.inc.h files are its sections
+HEADERS = [os.path.join(os.path.dirname(HERE), "include", "sps_hip.h")] + sorted(
+    os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".inc.h"))
 
 
 def hipcc_path() -> str:

@@ -1,0 +1,289 @@
+// aux_kernels.inc.h -- part of the single translation unit sps_hip.hip (included inside its anonymous namespace).
+// slice/metrics, variant-A / variant-B submaps, small utility kernels.
+
+// ------------------------------------------------------------------------------------------
+// metrics (models.py:84-105, util.py:285-299): per batch index accumulators over scan rows
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_metrics(const float *__restrict__ scores, const float *__restrict__ batch, int64_t ld, int n,
+                          float eps, int n_batches, double *__restrict__ acc) {
+  // Few workgroups, each thread accumulates its rows in registers; a thread flushes early only when
+  // the batch index of its rows changes (rows are grouped by b), so the 8 accumulators of a batch
+  // index see ~one atomic per workgroup instead of one per 256 rows.
+  __shared__ double red[8][4];
+  __shared__ int bsh[4];
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int b = -1;
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+    const float *row = batch + (size_t)p * ld;
+    if (row[4] != 1.0f) continue;  // scan rows only (t == 1)
+    const int bi = (int)row[0];
+    if (bi < 0 || bi >= n_batches) continue;
+    if (bi != b) {
+      if (b >= 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if (v[j] != 0.0) atomicAdd(&acc[b * 8 + j], v[j]);
+          v[j] = 0.0;
+        }
+      }
+      b = bi;
+    }
+    const float s = scores[p], g = row[5];
+    const int pred = s < eps ? 0 : 1, gt = g < eps ? 0 : 1;
+    const double d = (double)s - (double)g;
+    v[0] += 1;
+    v[1] += (gt == 1 && pred == 1);
+    v[2] += (gt == 0 && pred == 1);
+    v[3] += (gt == 1 && pred == 0);
+    v[4] += (gt == 0 && pred == 0);
+    v[5] += d * d;
+    v[6] += g;
+    v[7] += (double)g * (double)g;
+  }
+  // workgroup reduction when all its threads ended on the same batch index (the common case)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int bmax = b, bmin = b < 0 ? 0x7fffffff : b;
+  for (int o = 32; o > 0; o >>= 1) {
+    bmax = max(bmax, __shfl_xor(bmax, o, 64));
+    bmin = min(bmin, __shfl_xor(bmin, o, 64));
+  }
+  if (lane == 0) bsh[wave] = (bmax < 0) ? -1 : (bmin == bmax ? bmax : -2);
+  __syncthreads();
+  int wb = -1;
+  bool uniform = true;
+  for (int i = 0; i < 4; ++i) {
+    const int x = bsh[i];
+    if (x == -2) uniform = false;
+    else if (x >= 0) {
+      if (wb >= 0 && wb != x) uniform = false;
+      wb = x;
+    }
+  }
+  if (wb < 0 && uniform) return;
+  if (uniform) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      double x = v[j];
+      for (int o = 32; o > 0; o >>= 1) x += __shfl_down(x, o, 64);
+      if (lane == 0) red[j][wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+      const double x = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+      if (x != 0.0) atomicAdd(&acc[wb * 8 + threadIdx.x], x);
+    }
+  } else if (b >= 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (v[j] != 0.0) atomicAdd(&acc[b * 8 + j], v[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// variant-B submap (util.py:67-114): trunc grid, map hash resident on the device
+// ------------------------------------------------------------------------------------------
+__device__ inline bool trunc_key(const float *c, float ds, uint64_t &key) {
+  // torch: (xyz / ds).int() -> f32 division, truncation toward zero
+  const float fx = truncf(__fdiv_rn(c[0], ds)), fy = truncf(__fdiv_rn(c[1], ds)), fz = truncf(__fdiv_rn(c[2], ds));
+  const bool ok = fx >= (float)SPS_COORD_MIN && fx <= (float)SPS_COORD_MAX && fy >= (float)SPS_COORD_MIN &&
+                  fy <= (float)SPS_COORD_MAX && fz >= (float)SPS_COORD_MIN && fz <= (float)SPS_COORD_MAX;
+  if (!ok) return false;
+  key = key_pack(0, (int)fx, (int)fy, (int)fz, 0);
+  return true;
+}
+
+__device__ inline bool ijk_key(const int32_t *c, uint64_t &key) {
+  if (!key_in_range(0, c[0], c[1], c[2], 0)) return false;
+  key = key_pack(0, c[0], c[1], c[2], 0);
+  return true;
+}
+
+// IJK = false: rows are float xyz (truncated here); IJK = true: rows are int32 voxel indices
+// (already truncated by util.to_coords_features).
+template <bool IJK>
+__global__ void k_map_insert(const void *__restrict__ src, int64_t ld, int64_t m, float ds, HashTable h, int *err) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= m) return;
+  uint64_t key;
+  const bool ok = IJK ? ijk_key((const int32_t *)src + (size_t)p * ld, key)
+                      : trunc_key((const float *)src + (size_t)p * ld, ds, key);
+  if (!ok) {
+    atomicOr(err, 1);
+    return;
+  }
+  hash_insert(h, key);
+}
+
+template <bool IJK>
+__global__ void k_scan_trunc_insert(const void *__restrict__ src, int64_t ld, int n, float ds, HashTable h,
+                                    uint64_t *__restrict__ srckey, int *__restrict__ pslot, int *err) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint64_t key;
+  const bool ok = IJK ? ijk_key((const int32_t *)src + (size_t)p * ld, key)
+                      : trunc_key((const float *)src + (size_t)p * ld, ds, key);
+  if (!ok) {
+    atomicOr(err, 1);
+    srckey[p] = KEY_EMPTY;
+    pslot[p] = -1;
+    return;
+  }
+  const int s = hash_insert(h, key);
+  atomicMin(&h.first[s], p);
+  srckey[p] = key;
+  pslot[p] = s;
+}
+
+// After the first-occurrence pass: keep the unique scan voxels that exist in the map hash.
+// Turns pslot into -1 for non-first / non-hit points so that the generic count/rank passes compact
+// exactly the intersection, in scan first-occurrence order.  counts[0] += number of unique scan voxels.
+__global__ void k_submap_filter(int *__restrict__ pslot, const int *first, const uint64_t *__restrict__ srckey, int n,
+                                HashTable map, int *__restrict__ keep, int *__restrict__ n_scan_vox) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  int uniq = 0, k = 0;
+  if (p < n) {
+    const int s = pslot[p];
+    if (s >= 0 && first[s] == p) {
+      uniq = 1;
+      k = hash_find_slot(map, srckey[p]) >= 0;
+    }
+    keep[p] = k;
+  }
+  const unsigned long long bal = __ballot(uniq);
+  if ((threadIdx.x & 63) == 0 && bal) atomicAdd(n_scan_vox, __popcll(bal));
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_keep_count(const int *__restrict__ keep, int n,
+                                                            int *__restrict__ block_sums) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int flag = p < n ? keep[p] : 0;
+  const int tot = block_reduce_sum(flag, lds);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_keep_write(const int *__restrict__ keep,
+                                                            const uint64_t *__restrict__ srckey, int n, float ds,
+                                                            const int *__restrict__ block_sums,
+                                                            float *__restrict__ out_xyz, int *__restrict__ count_out) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int wave_off[SCAN_BLOCK / 64];
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) part += block_sums[i];
+  const int base = block_reduce_sum(part, lds);
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int flag = p < n ? keep[p] : 0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_off[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+    const int c = wave_off[i];
+    if (i < wave) off += c;
+    tot += c;
+  }
+  if (flag) {
+    int b, x, y, z, t;
+    key_unpack(srckey[p], b, x, y, z, t);
+    float *o = out_xyz + (size_t)(base + off + in_wave) * 3;
+    // torch: int32 tensor * python float -> float32 (util.py:112)
+    o[0] = (float)x * ds;
+    o[1] = (float)y * ds;
+    o[2] = (float)z * ds;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_out = base + tot;
+}
+
+// ------------------------------------------------------------------------------------------
+// variant-A submap (blt_dataset.py:258-271): map points within Euclidean radius r of a scan point.
+// The map is binned once into a uniform grid of cell size >= r (sorted by cell, ascending point index
+// inside a cell); a query visits the 27 cells around the scan point and applies the exact float64 test
+// dx*dx + dy*dy + dz*dz <= r*r (no FMA contraction: same arithmetic as scipy's cKDTree leaf test).
+// ------------------------------------------------------------------------------------------
+struct RadiusGrid {
+  HashTable h;             // cell key -> cell id (rank)
+  const int *cell_start;   // [C + 1]
+  const int *cell_pts;     // [M] map point indices, grouped by cell
+  const double *xyz;       // [M, 3] map points (compact)
+  double inv_cell, r2;
+};
+
+__device__ inline bool radius_cell(double v, double inv_cell, long long &c) {
+  const double f = floor(v * inv_cell);
+  if (!(f >= -1048575.0 && f <= 1048575.0)) return false;
+  c = (long long)f;
+  return true;
+}
+__device__ inline uint64_t radius_key(long long cx, long long cy, long long cz) {
+  return ((uint64_t)(cz + 1048576) << 42) | ((uint64_t)(cy + 1048576) << 21) | (uint64_t)(cx + 1048576);
+}
+
+__global__ void k_radius_cells_insert(const unsigned long long *__restrict__ cell_keys, int ncell, HashTable h) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ncell) return;
+  const int s = hash_insert(h, cell_keys[i]);
+  h.rank[s] = i;
+}
+
+// One thread per (scan point i, neighbour cell c in 0..26; c = (dx+1) + 3(dy+1) + 9(dz+1)).
+// MODE 0: counts[i*27 + c] = hits of point i in that cell.  MODE 1: write them at offsets[i*27 + c].
+// A point's list is therefore ordered by cell, ascending map index inside a cell.
+template <int MODE>
+__global__ void k_radius_query(const double *__restrict__ scan, int64_t ld, int n, RadiusGrid g,
+                               int *__restrict__ counts, const int64_t *__restrict__ offsets,
+                               int64_t *__restrict__ out) {
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= (int64_t)n * 27) return;
+  const int i = (int)(tid / 27), c27 = (int)(tid - (int64_t)i * 27);
+  const double px = scan[(size_t)i * ld], py = scan[(size_t)i * ld + 1], pz = scan[(size_t)i * ld + 2];
+  long long cx, cy, cz;
+  int cnt = 0;
+  int64_t *dst = MODE == 1 ? out + offsets[tid] : nullptr;
+  if (radius_cell(px, g.inv_cell, cx) && radius_cell(py, g.inv_cell, cy) && radius_cell(pz, g.inv_cell, cz)) {
+    const int s = hash_find_slot(g.h, radius_key(cx + (c27 % 3 - 1), cy + ((c27 / 3) % 3 - 1), cz + (c27 / 9 - 1)));
+    if (s >= 0) {
+      const int c = g.h.rank[s];
+      for (int t = g.cell_start[c]; t < g.cell_start[c + 1]; ++t) {
+        const int j = g.cell_pts[t];
+        const double ex = px - g.xyz[(size_t)j * 3], ey = py - g.xyz[(size_t)j * 3 + 1], ez = pz - g.xyz[(size_t)j * 3 + 2];
+        const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
+        if (d2 <= g.r2) {
+          if (MODE == 1) dst[cnt] = j;
+          ++cnt;
+        }
+      }
+    }
+  }
+  if (MODE == 0) counts[tid] = cnt;
+}
+
+// ------------------------------------------------------------------------------------------
+// small utility kernels
+// ------------------------------------------------------------------------------------------
+__global__ void k_rows_to_coords(const int *__restrict__ vblock, const unsigned char *__restrict__ vbit,
+                                 const uint64_t *__restrict__ bkey, int level, int n, int32_t *__restrict__ out) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= n) return;
+  const uint64_t key = bkey[vblock[v]];
+  const int bit = vbit[v];
+  const int bx = (int)(key & 0x3FFFF), by = (int)((key >> 18) & 0x3FFFF), bz = (int)((key >> 36) & 0x3FFFF);
+  int32_t *o = out + (size_t)v * 5;
+  o[0] = (int)(key >> 59);
+  o[1] = (((bx << 2) | (bit & 3)) << level) - XBIAS;
+  o[2] = (((by << 2) | ((bit >> 2) & 3)) << level) - XBIAS;
+  o[3] = (((bz << 2) | (bit >> 4)) << level) - XBIAS;
+  o[4] = (int)((key >> 54) & 0x1F) - TBIAS;
+}
+__global__ void k_i32_to_i64(const int *__restrict__ in, int n, int64_t *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+__global__ void k_copy_strided(const float *__restrict__ in, int ldi, int rows, int cols, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i % cols);
+  out[i] = in[(size_t)r * ldi + c];
+}
+

@@ -1,0 +1,609 @@
+// conv_kernels.inc.h -- part of the single translation unit sps_hip.hip (included inside its anonymous namespace).
+// sparse convolution kernels (f32 MFMA), conv0 fused with its map, split-K reduction, experimental row compaction.
+
+// ------------------------------------------------------------------------------------------
+// sparse convolution: output-stationary gather + f32 MFMA, fused BN / residual / ReLU epilogue
+// ------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+  const float *in;        // [*, ldi]
+  float *out;             // [*, ldo]
+  const float *Wu;        // unit-major permuted weights (see permute_weights)
+  const float *scale;     // [cout]  folded BN (or 1)
+  const float *shift;     // [cout]  folded BN (or bias)
+  const float *res;       // residual [*, ldr] or null
+  const int *nbr;         // [K][ldn] or null (identity, K == 1)
+  const uint32_t *tmask;  // [tiles][4] present-offset mask per 16-row tile, or null (K == 1)
+  const int *n_out;       // device count of output rows
+  float *slab;            // split-K partial sums [S][slab_stride] (S > 1)
+  int64_t ldn, slab_stride;
+  int ldi, ldo, ldr;
+  int K, cin, cout, NT, upk;
+  int relu, S;
+  float inv_upk;
+  float in_const;  // conv0: the constant input feature (0.5, models.py:22)
+  uint32_t in_bytes, wu_bytes, nbr_bytes;  // extents of `in` / `Wu` / `nbr` for the buffer descriptors
+  // fused 1x1 "downsample" branch of a BasicBlock (resnet.py:98-108): upk2 extra units read from in2 at
+  // the output row itself, weights stored after the K*upk regular units (pre-scaled, see permute)
+  const float *in2;
+  int ldi2, upk2;
+  uint32_t in2_bytes;
+  // fused `final` 1x1 conv + bias (minkunet.py:152-158, C_out = 1): logits[row] = y[row,:] . fin_w + fin_b
+  const float *fin_w;
+  float *fin_out;
+  float fin_b;
+};
+
+// Output-stationary sparse convolution on f32 MFMA.
+//   One wave = one 16-row output tile x (NTW*16) output channels x one split of the tile's work list.
+//   Work list of a tile = the offsets k present for at least one of its rows (tile mask -> compact
+//   list, built in the prologue), expanded to "units" (k, c4) of 4 consecutive input channels.
+//   v_mfma_f32_16x16x4_f32 lane map (cdna_hip_programming.md section 3): lane l holds A[l&15][l>>4] and
+//   B[l>>4][l&15].  Lane group q = l>>4 walks units j = 4i+q of the list: it gathers ONE float4 of its
+//   row (A) and ONE float4 of unit-major weights (B) and feeds them over 4 MFMA steps; the MFMA's
+//   K-sum adds the 4 lane groups, so the K order inside a step is a permutation of (k, ci) -- which a
+//   sum does not see; across steps offsets ascend as in ME (App. A.8).
+//   Weights: Wu[u][nt][n][s] = W[k][4*c4+s][16*nt+n], u = k*upk + c4 (zero padded to 16 columns), so a
+//   B fragment is one coalesced 16-byte load per lane (256 B per lane group).
+//   S > 1: the unit list is cut into S contiguous chunks (blockIdx.z), partial sums go to a slab and
+//   k_reduce_epilogue adds them in fixed order (bit-reproducible, no atomics).
+//   Latency structure: the neighbour rows of up to KCHUNK present offsets x 16 rows are first staged
+//   into LDS by all 64 lanes (independent, coalesced loads); the unit loop then issues the gathers
+//   and weight loads of G groups together before their 4*G*NTW MFMAs, so a wave has G (not 1)
+//   dependent-load round trips in flight.
+//   Instruction diet (the v2 kernel issued 11.6 VALU per MFMA, profiles/round1_pmc): LDS holds BYTE
+//   OFFSETS (row * ld * 4, k * bytes-per-offset); gathers and weight loads are buffer_load_dwordx4
+//   with a 32-bit voffset, so the address arithmetic is one add per load, and an absent neighbour is
+//   the out-of-range offset OOR, for which the hardware returns zeros (no branch, no select); (k, c4)
+//   advance incrementally instead of by division.
+constexpr int KCHUNK = 32;
+constexpr uint32_t OOR = 0xFFFF0000u;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int NTW, int G, int MINW, bool DS, bool FIN>
+__global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
+  __shared__ unsigned char klist[4][128];
+  __shared__ uint32_t aoff_s[4][KCHUNK * 16];
+  __shared__ uint32_t woff_s[4][KCHUNK];
+  const int count = *a.n_out;
+  const int ntiles = (count + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int nt0 = blockIdx.y * NTW;
+  const int split = blockIdx.z;
+  unsigned char *kl = klist[wave];
+  uint32_t *ao = aoff_s[wave];
+  uint32_t *wo = woff_s[wave];
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
+  const uint32_t ldn32 = (uint32_t)a.ldn;
+  const int upk = a.upk;
+  const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
+  const uint32_t wunit = (uint32_t)a.NT * 256u;            // bytes of one unit's weights (all column tiles)
+  const uint32_t wlane = (uint32_t)nt0 * 256u + (uint32_t)r * 16u;
+  const int kstep = 4 / upk, cstep = 4 % upk;              // unit index += 4 per group
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+    // ---- prologue: compact list of present offsets (wave-synchronous LDS)
+    int nk = 1;
+    __builtin_amdgcn_wave_barrier();
+    if (a.tmask) {
+      const uint32_t *m = a.tmask + (size_t)tile * 4;
+      const uint32_t w0 = m[lane >> 5], w1 = m[2 + (lane >> 5)];
+      const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = (w1 >> (lane & 31)) & 1u;
+      const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const int n0 = __popcll(bal0);
+      if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)lane;
+      if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(lane + 64);
+      nk = n0 + __popcll(bal1);
+    } else if (lane == 0) {
+      kl[0] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int U = nk * upk;
+    int per = (U + a.S - 1) / a.S;
+    per = (per + 3) & ~3;
+    const int j0 = split * per;
+    const int j1 = min(U, j0 + per);
+
+    floatx4 acc[NTW];
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    // offsets [kc, kc + nkc) of the list cover this wave's units [j0, j1)
+    const int kk_end = j1 > j0 ? (j1 - 1) / upk + 1 : 0;
+    for (int kc = j1 > j0 ? j0 / upk : 0; kc < kk_end; kc += KCHUNK) {
+      const int nkc = min(KCHUNK, kk_end - kc);
+      // ---- stage byte offsets of the chunk's neighbour rows: ao[kkl*16 + rr], and of its weights.
+      // Lane (q, r) owns row r for the offsets kc + q + 4i: all NST loads are issued before any is used.
+      __builtin_amdgcn_wave_barrier();
+      {
+        constexpr int NST = KCHUNK * 16 / 64;
+        const int row = row0 + r;
+        const bool rv = row < count;
+        int vals[NST];
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int kkl = q + 4 * i;
+          const bool act = rv && kkl < nkc;
+          if (a.nbr) {
+#if defined(SPS_ABLATE_STAGE)
+            vals[i] = act ? row : -1;
+#else
+            const uint32_t off = act ? ((uint32_t)kl[kc + kkl] * ldn32 + (uint32_t)row) * 4u : OOR;
+            vals[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
+#endif
+          } else {
+            vals[i] = row;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+          const int kkl = q + 4 * i;
+          const bool act = rv && kkl < nkc;
+          if (kkl < nkc) ao[kkl * 16 + r] = (act && vals[i] >= 0) ? (uint32_t)vals[i] * ldi4 : OOR;
+        }
+      }
+      if (lane < nkc) wo[lane] = (uint32_t)kl[kc + lane] * (uint32_t)upk * wunit;
+      __builtin_amdgcn_wave_barrier();
+      const int ju0 = max(j0, kc * upk), ju1 = min(j1, (kc + nkc) * upk);
+      // this lane's first unit of the chunk
+      int jl = ju0 + q;
+      int kk = (int)(((float)jl + 0.5f) * a.inv_upk);
+      int c4 = jl - kk * upk;
+      kk -= kc;
+      for (int jb = ju0; jb < ju1; jb += 4 * G) {
+        u32x4 va[G];
+        u32x4 vb[G][NTW];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const bool valid = jb + 4 * g + q < ju1;
+          const int kkc = min(kk, KCHUNK - 1);
+#if defined(SPS_ABLATE_A)
+          const uint32_t oa = OOR;
+          (void)ao;
+#else
+          const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
+#endif
+#if defined(SPS_ABLATE_B)
+          const uint32_t ob = OOR;
+#else
+          const uint32_t ob = valid ? wo[kkc] + (uint32_t)c4 * wunit + wlane : OOR;
+#endif
+          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+          c4 += cstep;
+          kk += kstep;
+          const int wrap = c4 >= upk ? 1 : 0;   // branch-free carry of the (k, c4) counter
+          c4 -= wrap ? upk : 0;
+          kk += wrap;
+        }
+#if defined(SPS_ABLATE_MFMA)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          asm volatile("" ::"v"(va[g].x), "v"(va[g].y), "v"(va[g].z), "v"(va[g].w));
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt)
+            asm volatile("" ::"v"(vb[g][nt].x), "v"(vb[g][nt].y), "v"(vb[g][nt].z), "v"(vb[g][nt].w));
+        }
+#else
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb[g][nt].x), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb[g][nt].y), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb[g][nt].z), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
+          }
+        }
+#endif
+      }
+    }
+    // ---- fused residual branch: r = downsample(x) = x[row] @ Wds (identity map), last split only
+    if (DS && split == a.S - 1) {
+      const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in2, 0, (int)a.in2_bytes, 0x00020000);
+      const int row = row0 + r;
+      const uint32_t rowoff = row < count ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) : OOR;
+      const uint32_t wbase = (uint32_t)(a.K * upk) * wunit + wlane;
+      for (int jb = 0; jb < a.upk2; jb += 4 * G) {
+        u32x4 va[G];
+        u32x4 vb[G][NTW];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          const int j = jb + 4 * g + q;
+          const bool valid = j < a.upk2;
+          const uint32_t oa = valid ? rowoff + (uint32_t)j * 16u : OOR;
+          const uint32_t ob = valid ? wbase + (uint32_t)j * wunit : OOR;
+          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, oa, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) {
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb[g][nt].x), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb[g][nt].y), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb[g][nt].z), acc[nt], 0, 0, 0);
+            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
+          }
+        }
+      }
+    }
+    // ---- epilogue.  C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+    if (NTW == 1 && FIN) {
+      // block8.conv2 + `final`: the 8 channels of a row sit in lanes r = 0..7 of its 16-lane group
+      const int col = r;
+      const bool cv = col < a.cout;
+      const float sc = cv ? a.scale[col] : 0.f, sh = cv ? a.shift[col] : 0.f, fw = cv ? a.fin_w[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        float y = acc[0][i] * sc + sh;
+        if (a.res && cv && ro < count) y += a.res[(size_t)ro * a.ldr + col];
+        if (a.relu) y = fmaxf(y, 0.f);
+        if (cv && ro < count) a.out[(size_t)ro * a.ldo + col] = y;
+        float t = y * fw;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        if (r == 0 && ro < count) a.fin_out[ro] = t + a.fin_b;
+      }
+      continue;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+      const int col = (nt0 + nt) * 16 + r;
+      if (col >= a.cout) continue;
+      if (a.S > 1) {
+        float *sl = a.slab + (size_t)split * a.slab_stride;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int ro = row0 + q * 4 + i;
+          if (ro < count) sl[(size_t)ro * a.cout + col] = acc[nt][i];
+        }
+        continue;
+      }
+      const float sc = a.scale[col], sh = a.shift[col];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        if (ro >= count) continue;
+        float y = acc[nt][i] * sc + sh;
+        if (a.res) y += a.res[(size_t)ro * a.ldr + col];
+        if (a.relu) y = fmaxf(y, 0.f);
+        a.out[(size_t)ro * a.ldo + col] = y;
+      }
+    }
+  }
+}
+
+// conv0p1s1 (5x5x5x1, 1 -> 8, minkunet.py:55-62) fused with its kernel map.  The input feature is
+// the constant 0.5 (models.py:22; mean of 0.5s, App. A.4), so only the PRESENCE of each of the 125
+// neighbours matters: out[u] = sum_{k present} 0.5 * W[k], k ascending (App. A.8), then BN + ReLU.
+// One wave = one 16-row tile.  Lane group q fetches the occupancy of the (dy,dz) runs q, q+4, ...
+// (the five dx neighbours of a run live in two adjacent blocks whose masks give five presence bits;
+// all loads of a lane are independent: two round trips in total), the 125-bit presence maps of the
+// four lane groups are OR-ed with two shuffles, and the convolution is 32 MFMAs with
+// A[row][k] = present ? 0.5 : 0 and B[k][n] = W[k][0][n] from LDS.  No neighbour table is materialised.
+__global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_out, LevelView L,
+                                                      const float *__restrict__ W, const float *__restrict__ scale,
+                                                      const float *__restrict__ shift, float in_const,
+                                                      float *__restrict__ out, int ldo) {
+  __shared__ float w_s[128 * 8];
+  for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
+  __syncthreads();
+  const int n = *n_out;
+  const int ntiles = (n + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+    const int u = row0 + r;
+    uint32_t bm[4] = {0u, 0u, 0u, 0u};
+#if defined(SPS_ABLATE_C0FETCH)
+    bm[0] = bm[1] = 0x0F0F0F0Fu;
+    if (false) {
+      const int blk = L.vblock[u];
+#else
+    if (u < n) {
+      const int blk = L.vblock[u];
+#endif
+      const int bit = L.vbit[u];
+      const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+      const int bo_lo = px < 2 ? -1 : 0;  // the dx run [px-2, px+2] touches blocks bo_lo and bo_lo + 1
+      const int *adj = L.badj + (size_t)blk * 81;
+      // two batches (4 + 3 runs) keep the kernel at 64 VGPRs = 8 waves per SIMD: one round for ~7k tiles
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        int nb0[4], nb1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = q + 4 * (4 * half + i);  // run index: dy = c % 5 - 2, dz = c / 5 - 2
+          const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
+          const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
+          const bool on = c < 25;
+          nb0[i] = on ? adj[ad0] : -1;
+          nb1[i] = on ? adj[ad0 + 1] : -1;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = q + 4 * (4 * half + i);
+          const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
+          const int sh = ((tz & 3) << 4) | ((ty & 3) << 2);
+          const uint32_t m0 = nb0[i] >= 0 ? (uint32_t)((L.bmask[nb0[i]] >> sh) & 0xFull) : 0u;
+          const uint32_t m1 = nb1[i] >= 0 ? (uint32_t)((L.bmask[nb1[i]] >> sh) & 0xFull) : 0u;
+          // window bit j = presence at tx = 4 * bo_lo + j; the run starts at tx = px - 2
+          const uint32_t pres = c < 25 ? (((m0 | (m1 << 4)) >> (px - 2 - 4 * bo_lo)) & 0x1Fu) : 0u;
+          const int k0 = 5 * c;  // k = 5 c + (dx + 2)
+          const unsigned long long wide = (unsigned long long)pres << (k0 & 31);
+          const int w0 = (k0 >> 5) & 3;
+          bm[0] |= w0 == 0 ? (uint32_t)wide : 0u;
+          bm[1] |= w0 == 1 ? (uint32_t)wide : (w0 == 0 ? (uint32_t)(wide >> 32) : 0u);
+          bm[2] |= w0 == 2 ? (uint32_t)wide : (w0 == 1 ? (uint32_t)(wide >> 32) : 0u);
+          bm[3] |= w0 == 3 ? (uint32_t)wide : (w0 == 2 ? (uint32_t)(wide >> 32) : 0u);
+        }
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      bm[w] |= __shfl_xor(bm[w], 16, 64);
+      bm[w] |= __shfl_xor(bm[w], 32, 64);
+    }
+    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const int k = 4 * g + q;  // (4g + q) >> 5 == g >> 3
+      const float av = ((bm[g >> 3] >> (k & 31)) & 1u) ? in_const : 0.f;
+      const float bv = r < 8 ? w_s[k * 8 + r] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (r < 8) {
+      const float sc = scale[r], sh = shift[r];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * sc + sh, 0.f);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Row-compacting sparse convolution (3x3x3x3 layers of the fine levels).
+//   k_conv above executes an MFMA row slot for every (16-row tile, present offset) pair although only
+//   43..56 % of the tile's rows have that neighbour (tools/compaction_stats.py).  Here one workgroup
+//   owns a 64-row SUPERTILE with lane = row: for an offset k, a ballot compacts the rows that have the
+//   neighbour into ceil(c/16) MFMA row slots (1.77x fewer slots at level 0, 1.5x at level 1), only those
+//   rows are gathered, and one weight fragment serves up to 64 rows.  The products are added into
+//   LDS accumulators owned by the issuing wave (ds_add_f32, single writer -> deterministic).  The 4 waves
+//   take interleaved quarters of the supertile's offset list; their partials are summed in fixed order
+//   in the epilogue (BN / residual branch / ReLU / `final` fused as in k_conv).
+// ------------------------------------------------------------------------------------------
+
+template <int NTW, int KB, int MINW, bool DS, bool FIN>
+__global__ __launch_bounds__(256, MINW) void k_conv_sc(ConvArgs a) {
+  // row 64 of acc_s / slots 64..127 of the lists are dummies: predicated-off lanes write there, so the
+  // hot loops are free of divergent branches (hipcc otherwise waits after every conditional load)
+  __shared__ float acc_s[4][65][NTW * 16];
+  __shared__ uint32_t loff_s[4][KB][128];
+  __shared__ unsigned char lrow_s[4][KB][128];
+  __shared__ unsigned char klist_s[4][128];
+  const int count = *a.n_out;
+  const int nst = (count + 63) >> 6;
+  const int ntile_total = (count + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsA2 =
+      __builtin_amdgcn_make_buffer_rsrc((void *)(DS ? a.in2 : a.in), 0, (int)(DS ? a.in2_bytes : a.in_bytes), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsM =
+      __builtin_amdgcn_make_buffer_rsrc((void *)a.tmask, 0, ntile_total * 16, 0x00020000);
+  const uint32_t ldn32 = (uint32_t)a.ldn;
+  const int upk = a.upk;
+  const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
+  const uint32_t wunit = (uint32_t)a.NT * 256u;
+  const uint32_t wlane = (uint32_t)r * 16u;
+  unsigned char *kl = klist_s[wave];
+  float(*acc)[NTW * 16] = acc_s[wave];
+  const unsigned long long lt = (1ull << lane) - 1ull;
+
+  for (int st = blockIdx.x; st < nst; st += gridDim.x) {
+    const int row0 = st * 64;
+    const int row = row0 + lane;
+    const bool rv = row < count;
+    // ---- masks: this lane's tile (4 words; tiles beyond the end read as 0) and the union over the
+    //      supertile's 4 tiles -> compact offset list
+    const u32x4 twv = __builtin_amdgcn_raw_buffer_load_b128(rsM, (uint32_t)((row0 >> 4) + q) * 16u, 0, 0);
+    const uint32_t tw0 = twv.x, tw1 = twv.y, tw2 = twv.z;
+    uint32_t un[4] = {twv.x, twv.y, twv.z, twv.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      un[w] |= __shfl_xor(un[w], 16, 64);
+      un[w] |= __shfl_xor(un[w], 32, 64);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool b0 = (((lane < 32 ? un[0] : un[1]) >> (lane & 31)) & 1u) != 0u;
+    const bool b1 = (((lane < 32 ? un[2] : un[3]) >> (lane & 31)) & 1u) != 0u;
+    const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
+    const int n0 = __popcll(bal0);
+    kl[b0 ? __popcll(bal0 & lt) : 127] = (unsigned char)lane;                 // slot 127: dummy
+    kl[b1 ? n0 + __popcll(bal1 & lt) : 127] = (unsigned char)(lane + 64);
+    const int nk = n0 + __popcll(bal1);
+    // ---- zero this wave's accumulators (consecutive lanes -> consecutive words: conflict-free)
+#pragma unroll
+    for (int e = 0; e < NTW * 16; ++e) {
+      const int id = e * 64 + lane;
+      acc[id / (NTW * 16)][id % (NTW * 16)] = 0.f;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- this wave's offsets: list entries wave, wave + 4, ...   (+ the fused residual branch on wave 0)
+    const int nmine = nk > wave ? (nk - wave + 3) >> 2 : 0;
+    const int nextra = (DS && wave == 0) ? 1 : 0;  // virtual offset: x[row] @ Wds with every row present
+    for (int jb = 0; jb < nmine + nextra; jb += KB) {
+      // stage KB offsets: neighbour rows -> ballot -> compacted byte offsets + original rows
+      int kk[KB], cnt[KB];
+      int idx[KB];
+#pragma unroll
+      for (int b = 0; b < KB; ++b) {
+        const int j = jb + b;
+        const int k = (int)kl[min(wave + 4 * j, 126)];
+        kk[b] = j < nmine ? k : -1;  // -1: the residual branch (or nothing)
+        const uint32_t w = k < 32 ? tw0 : (k < 64 ? tw1 : tw2);
+        const bool has = j < nmine && rv && ((w >> (k & 31)) & 1u);
+        const uint32_t off = has ? ((uint32_t)k * ldn32 + (uint32_t)row) * 4u : OOR;
+        const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
+        idx[b] = has ? v : -1;
+      }
+#pragma unroll
+      for (int b = 0; b < KB; ++b) {
+        const int j = jb + b;
+        const bool extra = DS && nextra && j == nmine;
+        const bool pr = extra ? rv : idx[b] >= 0;
+        const unsigned long long bal = __ballot(pr);
+        cnt[b] = __popcll(bal);
+        const int rk = pr ? __popcll(bal & lt) : 64 + lane;
+        loff_s[wave][b][rk] = extra ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) : (uint32_t)idx[b] * ldi4;
+        lrow_s[wave][b][rk] = (unsigned char)lane;
+      }
+      __builtin_amdgcn_wave_barrier();
+      // process the batch: chunk level ch (16 compacted rows each), all staged offsets together
+      int maxc = 0;
+#pragma unroll
+      for (int b = 0; b < KB; ++b) maxc = max(maxc, cnt[b]);
+      for (int ch = 0; ch * 16 < maxc; ++ch) {
+        floatx4 d[KB][NTW];
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) d[b][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+        uint32_t abase[KB], wbase[KB];
+        int nu[KB];  // units of the item in this chunk (0 = nothing to do)
+        int gmax = 0;
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          const int j = jb + b;
+          const bool extra = DS && nextra && j == nmine;
+          const int slot = ch * 16 + r;
+          const uint32_t lo = loff_s[wave][b][slot];
+          abase[b] = slot < cnt[b] ? lo : OOR;
+          const int ku = extra ? a.K * upk : kk[b] * upk;  // first unit of the offset in Wu
+          wbase[b] = (uint32_t)ku * wunit + wlane;
+          nu[b] = ch * 16 < cnt[b] ? (extra ? a.upk2 : upk) : 0;
+          gmax = max(gmax, (nu[b] + 3) >> 2);
+        }
+        for (int gg = 0; gg < gmax; ++gg) {
+          u32x4 va[KB];
+          u32x4 vb[KB][NTW];
+          const int c4 = 4 * gg + q;
+#pragma unroll
+          for (int b = 0; b < KB; ++b) {
+            const int j = jb + b;
+            const bool extra = DS && nextra && j == nmine;
+            const bool on = c4 < nu[b];
+            const uint32_t oa = on ? abase[b] + (uint32_t)c4 * 16u : OOR;
+            const uint32_t ob = on ? wbase[b] + (uint32_t)c4 * wunit : OOR;
+            va[b] = (DS && extra) ? __builtin_amdgcn_raw_buffer_load_b128(rsA2, oa, 0, 0)
+                                  : __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) vb[b][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+          }
+          // out-of-range operands are zeros: the MFMAs of exhausted items add nothing (no branch)
+#pragma unroll
+          for (int b = 0; b < KB; ++b) {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].x), __uint_as_float(vb[b][nt].x), d[b][nt], 0, 0, 0);
+              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].y), __uint_as_float(vb[b][nt].y), d[b][nt], 0, 0, 0);
+              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].z), __uint_as_float(vb[b][nt].z), d[b][nt], 0, 0, 0);
+              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].w), __uint_as_float(vb[b][nt].w), d[b][nt], 0, 0, 0);
+            }
+          }
+        }
+        // scatter-add the chunk's results to the rows they belong to (D map: col = r, row slot = q*4 + i).
+        // Plain read-add-write: this wave is the only writer of acc, a row occurs once per item, and LDS
+        // operations of a wave execute in order (ds_add_f32 costs ~190 LDS cycles per instruction here).
+        // The four row bytes of a lane are one aligned 32-bit read; slots beyond cnt go to dummy row 64.
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          const uint32_t rows4 = *reinterpret_cast<const uint32_t *>(&lrow_s[wave][b][ch * 16 + q * 4]);
+          float *dst[4];
+          float cur[4][NTW];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int slot = ch * 16 + q * 4 + i;
+            const int orow = slot < cnt[b] ? (int)((rows4 >> (8 * i)) & 0xFFu) : 64;
+            dst[i] = &acc[orow][r];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) cur[i][nt] = dst[i][nt * 16];
+          }
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) dst[i][nt * 16] = cur[i][nt] + d[b][nt][i];
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    // ---- epilogue: sum the 4 waves' partials in fixed order, BN shift/scale, residual, ReLU, store
+#pragma unroll
+    for (int e = 0; e < NTW * 4; ++e) {
+      const int id = e * 256 + threadIdx.x;
+      const int rr = id / (NTW * 16), col = id % (NTW * 16);
+      const int ro = row0 + rr;
+      const float sum = ((acc_s[0][rr][col] + acc_s[1][rr][col]) + acc_s[2][rr][col]) + acc_s[3][rr][col];
+      const bool cv = col < a.cout;
+      float y = 0.f;
+      if (cv) {
+        y = sum * a.scale[col] + a.shift[col];
+        if (a.res && ro < count) y += a.res[(size_t)ro * a.ldr + col];
+        if (a.relu) y = fmaxf(y, 0.f);
+        if (ro < count) a.out[(size_t)ro * a.ldo + col] = y;
+      }
+      if (FIN && NTW == 1) {  // `final`: 16 consecutive threads hold one row
+        float t = cv ? y * a.fin_w[col] : 0.f;
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        if ((threadIdx.x & 15) == 0 && ro < count) a.fin_out[ro] = t + a.fin_b;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// split-K tail: out = epilogue(sum_s slab[s]) with s ascending (deterministic).
+__global__ void k_reduce_epilogue(ConvArgs a) {
+  const int count = *a.n_out;
+  const int64_t total = (int64_t)count * a.cout;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ro = (int)(i / a.cout), col = (int)(i - (int64_t)ro * a.cout);
+    float sum = 0.f;
+    for (int s = 0; s < a.S; ++s) sum += a.slab[(size_t)s * a.slab_stride + i];
+    float y = sum * a.scale[col] + a.shift[col];
+    if (a.res) y += a.res[(size_t)ro * a.ldr + col];
+    if (a.relu) y = fmaxf(y, 0.f);
+    a.out[(size_t)ro * a.ldo + col] = y;
+  }
+}
+
+// slice (models.py:28) + sigmoid (models.py:29)
+__global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__restrict__ inv, int n,
+                                float *__restrict__ scores) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = inv[p];
+  scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
+}
+

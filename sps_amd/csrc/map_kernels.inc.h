@@ -1,0 +1,170 @@
+// map_kernels.inc.h -- part of the single translation unit sps_hip.hip (included inside its anonymous namespace).
+// kernel maps: output-stationary neighbour tables + per-tile present-offset masks.
+
+// ------------------------------------------------------------------------------------------
+// kernel maps (output-stationary neighbour tables + per-tile offset masks)
+// ------------------------------------------------------------------------------------------
+enum NbrKind { NBR_3333 = 0, NBR_5551 = 1 };
+
+struct LevelView {
+  const int *vblock;
+  const unsigned char *vbit;
+  const uint64_t *bkey;
+  const unsigned long long *bmask;
+  const int *bbase;
+  const int *badj;
+  const int *bparent;
+  const int *bchild;
+};
+
+// bit k of tile (u >> 4): "some row of the 16-row tile has a neighbour through offset k".
+// blockDim.x and the grid stride are multiples of 64, so a 16-lane segment of a wave is one tile.
+__device__ inline bool tile_mask_or(uint32_t *tmask, int u, int k, bool present) {
+  const unsigned long long bal = __ballot(present);
+  const int lane = threadIdx.x & 63;
+  const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile is present
+  if ((lane & 15) == 0 && any) atomicOr(&tmask[(size_t)(u >> 4) * 4 + (k >> 5)], 1u << (k & 31));
+  return any;
+}
+
+// Per-level arguments of the flattened multi-level map kernels: workgroup blockIdx.x belongs to the
+// level l with chunk_off[l] <= blockIdx.x < chunk_off[l+1] and handles rows
+// (blockIdx.x - chunk_off[l]) * 256 ... of that level (grid-stride over chunks[l] workgroups).
+struct MapsArgs {
+  LevelView L[NLV];
+  int *nbr3[NLV];
+  uint32_t *tm3[NLV];
+  int *down[NLV], *up[NLV], *parent_row[NLV];  // index = coarse level (1..4)
+  uint32_t *tmdown[NLV], *tmup[NLV];
+  const int *counts;
+  int chunk_off[NLV + 1];
+  int64_t ldn;
+};
+
+__device__ inline int level_of_chunk(const MapsArgs &a, int first_level, int &local) {
+  int l = first_level;
+  while (l + 1 < NLV && (int)blockIdx.x >= a.chunk_off[l + 1]) ++l;
+  local = (int)blockIdx.x - a.chunk_off[l];
+  return l;
+}
+
+// Rows of the voxels at (position of (r, bit)) + (dx, dy, dz, dt) for dx = -R..R, written to
+// nbr[(k0 + dx + R) * ldn + u]: the dx run touches at most two neighbour blocks, whose adjacency /
+// mask / base are fetched once.
+template <int R>
+__device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int dt, int k0, int *__restrict__ nbr,
+                                  int64_t ldn, uint32_t *__restrict__ tmask) {
+  const int r = L.vblock[u];
+  const int bit = L.vbit[u];
+  const int px = bit & 3, ty = ((bit >> 2) & 3) + dy, tz = (bit >> 4) + dz;
+  const int ad0 = (dt + 1) * 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
+  const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
+  int last_bo = 99, base = 0;
+  unsigned long long mk = 0ull;
+#pragma unroll
+  for (int dx = -R; dx <= R; ++dx) {
+    const int tx = px + dx;
+    const int bo = tx >> 2;
+    if (bo != last_bo) {
+      last_bo = bo;
+      const int nb = L.badj[(size_t)r * 81 + ad0 + bo];
+      mk = nb >= 0 ? L.bmask[nb] : 0ull;
+      base = nb >= 0 ? L.bbase[nb] : 0;
+    }
+    const int nbit = nbit0 | (tx & 3);
+    int row = -1;
+    if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
+    const int k = k0 + dx + R;
+    // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
+    if (tile_mask_or(tmask, u, k, row >= 0)) nbr[(size_t)k * ldn + u] = row;
+  }
+}
+
+// nbr[k*ldn + u] = row of the voxel at (coordinate of u) + offset_k, or -1   (App. A.6-A.8)
+//   3x3x3x3 (all levels): k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1); blockIdx.y = (dy,dz,dt) combo
+// offsets are in units of the level's stride (the block grid already is).
+__global__ __launch_bounds__(256) void k_build_nbr3(MapsArgs a) {
+  int local;
+  const int l = level_of_chunk(a, 0, local);
+  const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
+  const int n = a.counts[l];
+  const int c = blockIdx.y;  // 0..26
+  const int dy = c % 3 - 1, dz = (c / 3) % 3 - 1, dt = c / 9 - 1;
+  const LevelView L = a.L[l];
+  for (int u = local * 256 + threadIdx.x; u < n; u += nchunks * 256)
+    lookup_run<1>(L, u, dy, dz, dt, 3 * c, a.nbr3[l], a.ldn, a.tm3[l]);
+}
+
+//   5x5x5x1 (level 0): k = (dx+2) + 5(dy+2) + 25(dz+2); blockIdx.y = (dy,dz) combo
+__global__ __launch_bounds__(256) void k_build_nbr5(const int *__restrict__ n_out, LevelView L, int *__restrict__ nbr,
+                                                     int64_t ldn, uint32_t *__restrict__ tmask) {
+  const int n = *n_out;
+  const int c = blockIdx.y;  // 0..24
+  const int dy = c % 5 - 2, dz = c / 5 - 2;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
+    lookup_run<2>(L, u, dy, dz, 0, 5 * c, nbr, ldn, tmask);
+}
+
+// Stride maps of all four level pairs in one launch.  chunk_off here is indexed by the FINE level
+// f = 0..3 (coarse level c = f + 1); each workgroup does both directions for its rows:
+//  down (App. A.9):  out = coarse voxel u, children at u + {0,1}^3 (fine units), k = dx + 2dy + 4dz
+//  up   (App. A.10): fine voxel v receives exactly one term, from its parent, through offset
+//                    k = position of v inside the parent: up[k*ldn + v] = (k == oct(v)) ? parent : -1
+__global__ __launch_bounds__(256) void k_build_stride_maps(MapsArgs a) {
+  int local;
+  const int f = level_of_chunk(a, 0, local);
+  if (f >= NLV - 1) return;
+  const int c = f + 1;
+  const int nchunks = a.chunk_off[f + 1] - a.chunk_off[f];
+  const LevelView F = a.L[f], C = a.L[c];
+  const int nf = a.counts[f], nc = a.counts[c];
+  // ---- up map + parent rows (rows = fine voxels)
+  for (int v = local * 256 + threadIdx.x; v < nf; v += nchunks * 256) {
+    const int r = F.vblock[v];
+    const int bit = F.vbit[v];
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const uint64_t key = F.bkey[r];
+    const int ox = (int)(key & 1), oy = (int)((key >> 18) & 1), oz = (int)((key >> 36) & 1);
+    const int pr = F.bparent[r];
+    const int pbit = ((oz * 2 + (pz >> 1)) << 4) | ((oy * 2 + (py >> 1)) << 2) | (ox * 2 + (px >> 1));
+    const int par = C.bbase[pr] + __popcll(C.bmask[pr] & ((1ull << pbit) - 1ull));
+    const int oct = (px & 1) | ((py & 1) << 1) | ((pz & 1) << 2);
+    a.parent_row[c][v] = par;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      a.up[c][(size_t)k * a.ldn + v] = (k == oct) ? par : -1;
+      tile_mask_or(a.tmup[c], v, k, k == oct);
+    }
+  }
+  // ---- down map (rows = coarse voxels)
+  for (int u = local * 256 + threadIdx.x; u < nc; u += nchunks * 256) {
+    const int r = C.vblock[u];
+    const int bit = C.vbit[u];
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const int cb = C.bchild[(size_t)r * 8 + ((px >> 1) | ((py >> 1) << 1) | ((pz >> 1) << 2))];
+    const unsigned long long mk = cb >= 0 ? F.bmask[cb] : 0ull;
+    const int base = cb >= 0 ? F.bbase[cb] : 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
+      const int cbit = ((((pz & 1) << 1) + dz) << 4) | ((((py & 1) << 1) + dy) << 2) | (((px & 1) << 1) + dx);
+      int row = -1;
+      if ((mk >> cbit) & 1ull) row = base + __popcll(mk & ((1ull << cbit) - 1ull));
+      a.down[c][(size_t)k * a.ldn + u] = row;
+      tile_mask_or(a.tmdown[c], u, k, row >= 0);
+    }
+  }
+}
+
+__global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, const int *__restrict__ n_ptr,
+                              const uint32_t *__restrict__ tmask, unsigned long long *__restrict__ pairs) {
+  const int n = *n_ptr;
+  const int k = blockIdx.y;
+  int c = 0;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
+    if ((tmask[(size_t)(u >> 4) * 4 + (k >> 5)] >> (k & 31)) & 1u)  // entries of absent (tile, k) are never written
+      c += nbr[(size_t)k * ldn + u] >= 0;
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pairs[k], (unsigned long long)c);
+}
+
