@@ -58,8 +58,8 @@ def synthetic_weights(net, seed=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
     ap.add_argument("--streams", type=int, default=16,
                     help="independent scans in flight per GPU (one HIP stream + native context each); 1 = strictly serial")
