@@ -62,6 +62,32 @@ int fail(int code, const char *fmt, ...) {
     if (e_ != hipSuccess) return fail(SPS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
   } while (0)
 
+// conv kernel instantiation parameters per column-tile count NTW: groups of loads in flight (G) and minimum
+// waves per SIMD (W); tools/tune_conv.sh sweeps them with -D flags.  (A double-buffered, software-pipelined
+// variant of the unit loop was measured too: no gain -- the fine-level layers are co-limited by the CU's L1
+// throughput for the gathers and by MFMA issue, not by latency.)
+#ifndef SPS_G1
+#define SPS_G1 4
+#endif
+#ifndef SPS_G1DS
+#define SPS_G1DS 3
+#endif
+#ifndef SPS_W1
+#define SPS_W1 7
+#endif
+#ifndef SPS_G2
+#define SPS_G2 2
+#endif
+#ifndef SPS_W2
+#define SPS_W2 6
+#endif
+#ifndef SPS_G4
+#define SPS_G4 2
+#endif
+#ifndef SPS_W4
+#define SPS_W4 4
+#endif
+
 #include "keys_hash.inc.h"
 #include "grid_kernels.inc.h"
 #include "map_kernels.inc.h"
@@ -475,21 +501,21 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
   if (g.ntw == 1) {
     if (cc.fin)
-      hipLaunchKernelGGL((k_conv<1, 3, 7, true, true>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true>), grid, dim3(256), 0, st, a);
     else if (ds)
-      hipLaunchKernelGGL((k_conv<1, 3, 7, true, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, false>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<1, 4, 7, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_W1, false, false>), grid, dim3(256), 0, st, a);
   } else if (g.ntw == 2) {
     if (ds)
-      hipLaunchKernelGGL((k_conv<2, 2, 6, true, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, true, false>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<2, 2, 6, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, false, false>), grid, dim3(256), 0, st, a);
   } else {
     if (ds)
-      hipLaunchKernelGGL((k_conv<4, 2, 4, true, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, true, false>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<4, 2, 4, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, false, false>), grid, dim3(256), 0, st, a);
   }
   if (g.S > 1) hipLaunchKernelGGL(k_reduce_epilogue, dim3((unsigned)(gx < 256 ? gx : 256)), dim3(256), 0, st, a);
   return SPS_OK;
