@@ -67,7 +67,7 @@ int fail(int code, const char *fmt, ...) {
 // variant of the unit loop was measured too: no gain -- the fine-level layers are co-limited by the CU's L1
 // throughput for the gathers and by MFMA issue, not by latency.)
 #ifndef SPS_G1
-#define SPS_G1 4
+#define SPS_G1 3
 #endif
 #ifndef SPS_G1DS
 #define SPS_G1DS 3

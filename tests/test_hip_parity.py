@@ -424,3 +424,54 @@ def test_variant_a_radius_submap_matches_scipy():
     a = np.unique(O.quantize(np.pad(item[:, :4], ((0, 0), (1, 0))), r), axis=0)
     b = np.unique(O.quantize(np.pad(ref_item[:, :4], ((0, 0), (1, 0))), r), axis=0)
     np.testing.assert_array_equal(a, b)
+
+
+def _structured_cloud(rng, kind):
+    """Small adversarial clouds: [N,6] float32 (b,x,y,z,t,label)."""
+    if kind == "dense_cube":                     # every voxel of a 12^3 cube, two time slices: all 81 offsets occur
+        g = np.stack(np.meshgrid(*[np.arange(12)] * 3, indexing="ij"), -1).reshape(-1, 3) * 0.1 + 0.05
+        xyz = np.concatenate([g, g[: len(g) // 2]], 0) - np.array([0.37, 0.61, 0.2])
+        t = np.concatenate([np.ones(len(g)), np.zeros(len(g) // 2)])
+    elif kind == "line":                         # a 1-voxel-wide diagonal line: almost no neighbours
+        s = np.linspace(-3, 3, 400)
+        xyz = np.stack([s, 0.7 * s, 0.2 * s], 1)
+        t = (np.arange(400) % 2).astype(float)
+    elif kind == "time_slices":                  # t in {-1,0,1,2}: dt = +-1 taps between every pair of slices (4DMOS-like)
+        xyz = rng.uniform(-1.5, 1.5, (1500, 3))
+        t = rng.integers(-1, 3, 1500).astype(float)
+    elif kind == "far_corner":                   # near the limits of the 18-bit voxel key (+-13.1 km at 0.1 m)
+        xyz = rng.uniform(-1.0, 1.0, (1200, 3)) + np.array([13090.0, -13090.0, 13000.0])
+        t = rng.integers(0, 2, 1200).astype(float)
+    elif kind == "duplicates":                   # 40 distinct points repeated 50 times, shuffled
+        base = rng.uniform(-0.5, 0.5, (40, 3))
+        idx = rng.integers(0, 40, 2000)
+        xyz = base[idx]
+        t = (idx % 2).astype(float)
+    else:                                        # "batches": three batch indices with very different sizes
+        xyz = rng.uniform(-2, 2, (2100, 3))
+        t = rng.integers(0, 2, 2100).astype(float)
+    n = len(xyz)
+    b = np.zeros(n)
+    if kind == "batches":
+        b = np.concatenate([np.zeros(2000), np.ones(90), np.full(10, 2)])
+    out = np.zeros((n, 6), np.float32)
+    out[:, 0] = b
+    out[:, 1:4] = xyz
+    out[:, 4] = t
+    out[:, 5] = rng.uniform(0, 1, n)
+    return out
+
+
+@pytest.mark.parametrize("kind", ["dense_cube", "line", "time_slices", "far_corner", "duplicates", "batches"])
+def test_structured_stress_cases(net, params, kind):
+    rng = np.random.default_rng({"dense_cube": 1, "line": 2, "time_slices": 3, "far_corner": 4, "duplicates": 5, "batches": 6}[kind])
+    batch = _structured_cloud(rng, kind)
+    if kind == "far_corner":
+        # float32 coordinates at 13 km have ~1 mm resolution: both sides quantise the SAME float32 values
+        check_full(net, params, batch, tol=5e-4)
+    else:
+        check_full(net, params, batch)
+    if kind == "dense_cube":
+        # interior voxels of the t = 1 cube see all 27 dt = 0 neighbours
+        p = ctx().map_pairs(0)
+        assert p[40] == ctx().level_counts()[0] and min(p[27:54]) > 0
