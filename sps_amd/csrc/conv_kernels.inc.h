@@ -84,6 +84,15 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const uint32_t wunit = (uint32_t)a.NT * 256u;            // bytes of one unit's weights (all column tiles)
   const uint32_t wlane = (uint32_t)nt0 * 256u + (uint32_t)r * 16u;
   const int kstep = 4 / upk, cstep = 4 % upk;              // unit index += 4 per group
+  // per-lane epilogue constants, fetched once (not after the MFMAs of every tile)
+  float esc[NTW], esh[NTW];
+#pragma unroll
+  for (int nt = 0; nt < NTW; ++nt) {
+    const int col = (nt0 + nt) * 16 + r;
+    esc[nt] = col < a.cout ? a.scale[col] : 0.f;
+    esh[nt] = col < a.cout ? a.shift[col] : 0.f;
+  }
+  const float efw = (FIN && r < a.cout) ? a.fin_w[r] : 0.f;
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
     const int row0 = tile * 16;
     // ---- prologue: compact list of present offsets (wave-synchronous LDS)
@@ -240,7 +249,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       // block8.conv2 + `final`: the 8 channels of a row sit in lanes r = 0..7 of its 16-lane group
       const int col = r;
       const bool cv = col < a.cout;
-      const float sc = cv ? a.scale[col] : 0.f, sh = cv ? a.shift[col] : 0.f, fw = cv ? a.fin_w[col] : 0.f;
+      const float sc = esc[0], sh = esh[0], fw = efw;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ro = row0 + q * 4 + i;
@@ -269,7 +278,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
         }
         continue;
       }
-      const float sc = a.scale[col], sh = a.shift[col];
+      const float sc = esc[nt], sh = esh[nt];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ro = row0 + q * 4 + i;
@@ -302,6 +311,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
   const int ntiles = (n + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
+  const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
     const int row0 = tile * 16;
     const int u = row0 + r;
@@ -364,11 +374,10 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
     if (r < 8) {
-      const float sc = scale[r], sh = shift[r];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ro = row0 + q * 4 + i;
-        if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * sc + sh, 0.f);
+        if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * esc + esh, 0.f);
       }
     }
   }
