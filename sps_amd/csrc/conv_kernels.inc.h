@@ -24,6 +24,7 @@ struct ConvArgs {
   float inv_upk;
   float in_const;  // conv0: the constant input feature (0.5, models.py:22)
   uint32_t in_bytes, wu_bytes, nbr_bytes;  // extents of `in` / `Wu` / `nbr` for the buffer descriptors
+  int tile_cap;                            // tiles the tmask buffer holds (cap / 16)
   // fused 1x1 "downsample" branch of a BasicBlock (resnet.py:98-108): upk2 extra units read from in2 at
   // the output row itself, weights stored after the K*upk regular units (pre-scaled, see permute)
   const float *in2;
@@ -93,14 +94,26 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
     esh[nt] = col < a.cout ? a.shift[col] : 0.f;
   }
   const float efw = (FIN && r < a.cout) ? a.fin_w[r] : 0.f;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  // the first tile's mask words do not depend on the row count: fetch them alongside it (saves a
+  // dependent round trip; tile_cap = tiles the mask buffer was allocated for)
+  const int tile_first = blockIdx.x * 4 + wave;
+  uint32_t pw0 = 0u, pw1 = 0u;
+  if (a.tmask && tile_first < a.tile_cap) {
+    pw0 = a.tmask[(size_t)tile_first * 4 + (lane >> 5)];
+    pw1 = a.tmask[(size_t)tile_first * 4 + 2 + (lane >> 5)];
+  }
+  for (int tile = tile_first; tile < ntiles; tile += gridDim.x * 4) {
     const int row0 = tile * 16;
     // ---- prologue: compact list of present offsets (wave-synchronous LDS)
     int nk = 1;
     __builtin_amdgcn_wave_barrier();
     if (a.tmask) {
-      const uint32_t *m = a.tmask + (size_t)tile * 4;
-      const uint32_t w0 = m[lane >> 5], w1 = m[2 + (lane >> 5)];
+      uint32_t w0 = pw0, w1 = pw1;
+      if (tile != tile_first) {
+        const uint32_t *m = a.tmask + (size_t)tile * 4;
+        w0 = m[lane >> 5];
+        w1 = m[2 + (lane >> 5)];
+      }
       const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = (w1 >> (lane & 31)) & 1u;
       const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
       const unsigned long long lt = (1ull << lane) - 1ull;

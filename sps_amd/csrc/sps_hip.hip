@@ -465,6 +465,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)cc.ldi * 4u);
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
   a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->cap * 4u);
+  a.tile_cap = (int)(c->cap / 16);
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
     hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
                        c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
