@@ -87,6 +87,29 @@ int sps_forward(sps_ctx *ctx, const float *coords_dev, int64_t ld, int64_t n, fl
  * met an unrepresentable coordinate. */
 int sps_check(sps_ctx *ctx, void *stream);
 
+/* ---- baseline heads on the same backbone ------------------------------
+ * The two baselines the reference ships run the SAME CustomMinkUNet14 wiring:
+ *   4DMOS  : MOS4DNet.forward  (reference c_ws/src/mos4d/scripts/mos4d.py:11-32) --
+ *            CustomMinkUNet(in_channels=1, out_channels=3), constant 0.5 feature, t = scan index of
+ *            a 10-scan buffer, voxel 0.2 m, returns the raw logits of column 2;
+ *   MapMOS : MapMOSNet.forward (reference c_ws/src/mapmos/scripts/mapmos.py:59-83) --
+ *            out_channels=1, a per-point feature (1 + normalised index) whose per-voxel mean
+ *            feeds conv0 (ME UNWEIGHTED_AVERAGE), t in {0,-1}, returns raw logits.
+ * sps_head_* describe the weight blob of a k-channel `final` (spec as sps_weights_*, with
+ * "final.kernel" [8,k] and "final.bias" [k]); sps_weights_load_head(…, k) loads it (k = 1 is
+ * sps_weights_load).  sps_forward_head:
+ *   feats_dev : float32 [n] per-point input feature, or NULL for the constant 0.5
+ *   t_base    : integer subtracted from floor(t) before hashing (the network is shift-invariant
+ *               along t; lets a long-running scan index fit the key's t range [-16,15])
+ *   out_dev   : float32 [n, out_channels] with row stride `ldo` floats (>= out_channels)
+ *   activation: 0 = raw logits, 1 = sigmoid */
+int sps_head_num_tensors(int out_channels);
+int sps_head_tensor_info(int out_channels, int idx, char *name, int name_cap, int64_t *offset, int64_t *numel);
+int64_t sps_head_numel(int out_channels);
+int sps_weights_load_head(sps_ctx *ctx, const float *blob_host, int64_t numel, int out_channels);
+int sps_forward_head(sps_ctx *ctx, const float *coords_dev, int64_t ld, int64_t n, float voxel_size,
+                     const float *feats_dev, float t_base, float *out_dev, int64_t ldo, int activation, void *stream);
+
 /* ---- metrics ------------------------------------------------------------------------
  * Replaces the per-scan part of SPSNet.predict_step (reference models.py:84-105) +
  * util.calculate_metrics (util.py:285-299).  For every batch index b < n_batches it

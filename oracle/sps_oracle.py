@@ -172,9 +172,10 @@ def relu(x):
 # --------------------------------------------------------------------------------------
 # parameter inventory (names as in the Lightning state_dict minus prefix)
 # --------------------------------------------------------------------------------------
-def layer_table():
+def layer_table(out_channels: int = 1):
     """Ordered list of (name, kind, K, C_in, C_out) for the 33 convolutions.
-    kind in {conv5, down, up, conv3, lin}."""
+    kind in {conv5, down, up, conv3, lin}.  ``out_channels`` = width of `final` (1 for SPS and MapMOS,
+    3 for 4DMOS: c_ws/src/mos4d/scripts/mos4d.py:15)."""
     t = [("conv0p1s1", "conv5", 125, 1, INIT_DIM)]
     enc_in = INIT_DIM
     downs = ["conv1p1s2", "conv2p2s2", "conv3p4s2", "conv4p8s2"]
@@ -190,7 +191,7 @@ def layer_table():
         cin = PLANES[4 + i] + skip[i]
         t += _block_entries(f"block{5 + i}", cin, PLANES[4 + i])
         cur = PLANES[4 + i]
-    t.append(("final", "lin", 1, PLANES[7], 1))
+    t.append(("final", "lin", 1, PLANES[7], out_channels))
     return t
 
 
@@ -222,17 +223,17 @@ def _block_bn(name, cin, cout):
     return e
 
 
-def random_params(seed=0, randomize_bn=True):
+def random_params(seed=0, randomize_bn=True, out_channels=1):
     """Synthetic weights: Kaiming-normal fan_out conv kernels
     (resnet.py:90; fan_out = K*C_out, std = sqrt(2/fan_out)), randomised BN statistics,
     final bias.  Keys follow the reference state_dict (App. B); 1x1 kernels are 2-D."""
     rng = np.random.default_rng(seed)
     p = {}
-    for name, kind, K, cin, cout in layer_table():
+    for name, kind, K, cin, cout in layer_table(out_channels):
         std = np.sqrt(2.0 / (K * cout))
         w = (rng.standard_normal((K, cin, cout)) * std).astype(F32)
         p[name + ".kernel"] = w[0] if kind == "lin" else w
-    p["final.bias"] = (rng.standard_normal((1, 1)) * 0.1).astype(F32)
+    p["final.bias"] = (rng.standard_normal((1, out_channels)) * 0.1).astype(F32)
     for name, c in bn_table():
         if randomize_bn:
             p[name + ".bn.weight"] = rng.uniform(0.5, 1.5, c).astype(F32)
@@ -369,6 +370,41 @@ def sps_forward(p, coordinates: np.ndarray, voxel_size: float, keep=False):
     scores = sigmoid(logits[inv, 0])                         # slice + sigmoid (A.15)
     info = {"voxels": vox, "inverse": inv, "logits": logits[:, 0], "cm": cm, "inter": inter}
     return scores, info
+
+
+def voxel_mean(features: np.ndarray, inverse: np.ndarray, n_vox: int) -> np.ndarray:
+    """TensorField.sparse() with ME's default UNWEIGHTED_AVERAGE (App. A.4): voxel feature = arithmetic
+    mean of its points' features; f32 accumulation in point order (CPU ME), then one division."""
+    acc = np.zeros(n_vox, dtype=F32)
+    cnt = np.zeros(n_vox, dtype=np.int64)
+    np.add.at(acc, inverse, features.astype(F32).reshape(-1))
+    np.add.at(cnt, inverse, 1)
+    return (acc / np.maximum(cnt, 1).astype(F32)).astype(F32).reshape(-1, 1)
+
+
+def head_forward(p, coordinates: np.ndarray, voxel_size: float, features=None, keep=False):
+    """The baseline heads on the same backbone: raw logits [N, out_channels] per point.
+      * 4DMOS  (c_ws/src/mos4d/scripts/mos4d.py:17-32): constant 0.5 feature, 3-channel `final`, caller takes
+        column 2;
+      * MapMOS (c_ws/src/mapmos/scripts/mapmos.py:59-83): ``features`` [N] per point, voxel mean, 1 channel."""
+    q = quantize(coordinates, voxel_size)
+    vox, inv = unique_first(q)
+    if features is None:
+        feats = np.full((len(vox), 1), 0.5, dtype=F32)
+    else:
+        feats = voxel_mean(np.asarray(features), inv, len(vox))
+    logits, cm, inter = unet_forward(p, vox, feats, keep=keep)
+    info = {"voxels": vox, "inverse": inv, "logits": logits, "voxel_features": feats, "cm": cm, "inter": inter}
+    return logits[inv], info
+
+
+def mapmos_features(indices: np.ndarray) -> np.ndarray:
+    """mapmos.py:65-71: 1 everywhere when all indices agree, else 1 + (i_max - i) / (i_max - i_min) in f32."""
+    idx = np.asarray(indices, dtype=F32).reshape(-1)
+    i_max, i_min = idx.max(), idx.min()
+    if i_max == i_min:
+        return np.ones_like(idx)
+    return (F32(1) + (i_max - idx) / (i_max - i_min)).astype(F32)
 
 
 # --------------------------------------------------------------------------------------

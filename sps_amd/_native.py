@@ -38,6 +38,11 @@ def _load() -> C.CDLL:
         "sps_weights_numel": (i64, []),
         "sps_weights_load": (i32, [vp, vp, i64]),
         "sps_forward": (i32, [vp, vp, i64, i64, f32, vp, vp]),
+        "sps_head_num_tensors": (i32, [i32]),
+        "sps_head_tensor_info": (i32, [i32, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
+        "sps_head_numel": (i64, [i32]),
+        "sps_weights_load_head": (i32, [vp, vp, i64, i32]),
+        "sps_forward_head": (i32, [vp, vp, i64, i64, f32, vp, f32, vp, i64, i32, vp]),
         "sps_check": (i32, [vp, vp]),
         "sps_metrics": (i32, [vp, vp, vp, i64, i64, f32, i32, C.POINTER(C.c_double), vp]),
         "sps_metrics_dev": (i32, [vp, vp, vp, i64, i64, f32, i32, vp, vp]),
@@ -71,7 +76,8 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
-           "sps_forward", "sps_check", "sps_metrics", "sps_metrics_dev",
+           "sps_forward", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
+           "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_radius_grid_upload", "sps_radius_count",
            "sps_radius_fill", "sps_level_counts", "sps_get_voxels",
@@ -83,13 +89,16 @@ def check(rc: int) -> None:
         raise SpsError(rc, lib.sps_last_error().decode())
 
 
-def weight_layout():
+def weight_layout(out_channels: int = 1):
     """[(name, offset, numel)] of the weight blob, from the library itself."""
     out = []
     buf = C.create_string_buffer(128)
     off, num = C.c_int64(), C.c_int64()
-    for i in range(lib.sps_weights_num_tensors()):
-        check(lib.sps_weights_tensor_info(i, buf, 128, C.byref(off), C.byref(num)))
+    n = lib.sps_head_num_tensors(out_channels)
+    if n < 0:
+        check(n)
+    for i in range(n):
+        check(lib.sps_head_tensor_info(out_channels, i, buf, 128, C.byref(off), C.byref(num)))
         out.append((buf.value.decode(), off.value, num.value))
     return out
 
@@ -118,8 +127,13 @@ class Context:
     def reserve(self, max_points: int):
         check(lib.sps_reserve(self.handle, int(max_points)))
 
-    def load_weights(self, blob_host_ptr: int, numel: int):
-        check(lib.sps_weights_load(self.handle, blob_host_ptr, int(numel)))
+    def load_weights(self, blob_host_ptr: int, numel: int, out_channels: int = 1):
+        check(lib.sps_weights_load_head(self.handle, blob_host_ptr, int(numel), int(out_channels)))
+
+    def forward_head(self, coords_ptr: int, ld: int, n: int, voxel_size: float, feats_ptr, t_base: float,
+                     out_ptr: int, ldo: int, activation: int, stream: int):
+        check(lib.sps_forward_head(self.handle, coords_ptr, ld, n, voxel_size, feats_ptr, t_base, out_ptr, ldo,
+                                   activation, stream))
 
     def forward(self, coords_ptr: int, ld: int, n: int, voxel_size: float, scores_ptr: int, stream: int):
         check(lib.sps_forward(self.handle, coords_ptr, ld, n, voxel_size, scores_ptr, stream))

@@ -620,6 +620,132 @@ __global__ void k_reduce_epilogue(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Head path: the baseline networks on the same backbone.
+//   MapMOS (c_ws/src/mapmos/scripts/mapmos.py:59-83) feeds a per-point feature whose per-voxel MEAN is
+//   the input of conv0 (ME TensorField.sparse(), UNWEIGHTED_AVERAGE, App. A.4); 4DMOS
+//   (c_ws/src/mos4d/scripts/mos4d.py:17-32) has a 3-channel `final` and returns raw logits.
+// ------------------------------------------------------------------------------------------
+
+// per-voxel sums in 32.32 fixed point: integer adds commute, so the mean is bit-reproducible run to run
+// (domain: |feature| < 2^15 and < 2^16 points per voxel; the error of the mean is < 2^-32)
+constexpr double FEAT_FIX = 4294967296.0;
+
+__global__ void k_voxel_feat_accum(const float *__restrict__ feats, const int *__restrict__ inv, int n,
+                                   long long *__restrict__ vacc, int *__restrict__ vcnt) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = inv[p];
+  if (v < 0) return;
+  const double f = fmin(fmax((double)feats[p], -32768.0), 32768.0);
+  atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + v, (unsigned long long)__double2ll_rn(f * FEAT_FIX));
+  atomicAdd(vcnt + v, 1);
+}
+
+__global__ void k_voxel_feat_mean(const int *__restrict__ n_vox, const long long *__restrict__ vacc,
+                                  const int *__restrict__ vcnt, float *__restrict__ vfeat) {
+  const int n = *n_vox;
+  for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
+    vfeat[v] = (float)(((double)vacc[v] / FEAT_FIX) / (double)max(vcnt[v], 1));
+}
+
+// conv0p1s1 (5x5x5x1, C_in = 1) on a non-constant voxel feature.  Same traversal as k_conv0_fused (per
+// row 25 runs of five x-neighbours read from the block occupancy masks), but each present neighbour's
+// ROW (block base + popcount below its bit) is resolved and its feature is placed in a per-wave LDS
+// panel A[16][125]; 32 MFMAs then contract it with W[k][0][0..7].
+__global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_out, LevelView L,
+                                                     const float *__restrict__ W, const float *__restrict__ scale,
+                                                     const float *__restrict__ shift,
+                                                     const float *__restrict__ vfeat, float *__restrict__ out,
+                                                     int ldo) {
+  __shared__ float w_s[128 * 8];
+  __shared__ float val_s[4][16][132];  // row stride 132: lane (r, q) reads bank 4r + q (+ 4g): conflict-free
+  for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
+  __syncthreads();
+  const int n = *n_out;
+  const int ntiles = (n + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
+  float *va = val_s[wave][r];
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+    const int u = row0 + r;
+    __builtin_amdgcn_wave_barrier();
+    for (int j = q; j < 128; j += 4) va[j] = 0.f;
+    __builtin_amdgcn_wave_barrier();
+    if (u < n) {
+      const int blk = L.vblock[u];
+      const int bit = L.vbit[u];
+      const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+      const int *adj = L.badj + (size_t)blk * 81;
+      for (int c = q; c < 25; c += 4) {  // run: dy = c % 5 - 2, dz = c / 5 - 2
+        const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
+        const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
+        const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
+        int last_bo = 99, base = 0;
+        unsigned long long mk = 0ull;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int tx = px + dx;
+          const int bo = tx >> 2;
+          if (bo != last_bo) {
+            last_bo = bo;
+            const int nb = adj[ad0 + bo];
+            mk = nb >= 0 ? L.bmask[nb] : 0ull;
+            base = nb >= 0 ? L.bbase[nb] : 0;
+          }
+          const int nbit = nbit0 | (tx & 3);
+          if ((mk >> nbit) & 1ull) va[5 * c + dx + 2] = vfeat[base + __popcll(mk & ((1ull << nbit) - 1ull))];
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < 32; ++g) {
+      const int k = 4 * g + q;
+      const float av = va[k];
+      const float bv = r < 8 ? w_s[k * 8 + r] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+    if (r < 8) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * esc + esh, 0.f);
+      }
+    }
+  }
+}
+
+// `final` 1x1 conv (+ bias) on block8's 8-channel output, slice to the points, optional sigmoid:
+//   out[p, j] = act(sum_c F[inv[p], c] * W[c, j] + b[j]),  j < oc     (minkunet.py:152-158, :217-219)
+__global__ void k_slice_head(const float *__restrict__ F, int ldf, const int *__restrict__ inv, int n,
+                             const float *__restrict__ W, const float *__restrict__ bias, int oc, int act,
+                             float *__restrict__ out, int64_t ldo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = inv[p];
+  float f[8];
+  if (v >= 0) {
+    const float4 a = *reinterpret_cast<const float4 *>(F + (size_t)v * ldf);
+    const float4 b = *reinterpret_cast<const float4 *>(F + (size_t)v * ldf + 4);
+    f[0] = a.x, f[1] = a.y, f[2] = a.z, f[3] = a.w, f[4] = b.x, f[5] = b.y, f[6] = b.z, f[7] = b.w;
+  }
+  for (int j = 0; j < oc; ++j) {
+    float y = __builtin_nanf("");
+    if (v >= 0) {
+      y = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) y += f[c] * W[c * oc + j];  // c ascending, as a [V,8] @ [8,oc] product
+      y += bias[j];
+      if (act == 1) y = 1.0f / (1.0f + expf(-y));
+    }
+    out[(size_t)p * ldo + j] = y;
+  }
+}
+
 // slice (models.py:28) + sigmoid (models.py:29)
 __global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__restrict__ inv, int n,
                                 float *__restrict__ scores) {

@@ -95,7 +95,7 @@ __device__ inline int wave_run_insert(const BHash &h, uint64_t key, bool ok, uin
 // point's block, set its occupancy bit.  Consecutive LiDAR returns mostly fall into the same block:
 // the wave elects one lane per distinct block, which issues the three atomics for the whole group.
 __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restrict__ coords, int64_t ld, int n, float vs,
-                                                           BHash h, int *__restrict__ sslot,
+                                                           float t_base, BHash h, int *__restrict__ sslot,
                                                            unsigned char *__restrict__ sbit, int *err) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   bool ok = false;
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restric
     const float fx = floorf(__fdiv_rn(c[1], vs));
     const float fy = floorf(__fdiv_rn(c[2], vs));
     const float fz = floorf(__fdiv_rn(c[3], vs));
-    const float ft = floorf(__fdiv_rn(c[4], 1.0f));
+    // t_base (integral; 0 on the SPS path): the network is shift-invariant along t (every stride is
+    // [2,2,2,1]), so the head path may re-base a long-running scan index into the key's 5-bit t field
+    const float ft = floorf(__fdiv_rn(c[4], 1.0f)) - t_base;
     // compare in float first so that huge / NaN values cannot overflow the int conversion
     ok = fb >= 0.f && fb <= (float)SPS_BATCH_MAX && ft >= (float)SPS_T_MIN && ft <= (float)SPS_T_MAX &&
          fx >= (float)SPS_COORD_MIN && fx <= (float)SPS_COORD_MAX && fy >= (float)SPS_COORD_MIN &&

@@ -34,6 +34,7 @@ struct NetSpec {
   std::vector<BnSpec> bns;
   std::vector<TensorInfo> tensors;
   int64_t numel = 0, ss_numel = 0, bias_off = 0, wu_numel = 0;
+  int out_channels = 1;  // C_out of `final` (1 = SPS / MapMOS, 3 = 4DMOS: c_ws/src/mos4d/scripts/mos4d.py:15)
   int find_conv(const std::string &n) const {
     for (size_t i = 0; i < convs.size(); ++i)
       if (convs[i].name == n) return (int)i;
@@ -58,8 +59,9 @@ void add_block(NetSpec &s, const std::string &name, int cin, int cout) {
   }
 }
 
-NetSpec build_spec() {
+NetSpec build_spec(int out_channels) {
   NetSpec s;
+  s.out_channels = out_channels;
   s.convs.push_back({"conv0p1s1", "bn0", 125, 1, INIT_DIM});
   s.bns.push_back({"bn0", INIT_DIM});
   const char *downs[4] = {"conv1p1s2", "conv2p2s2", "conv3p4s2", "conv4p8s2"};
@@ -78,7 +80,7 @@ NetSpec build_spec() {
     add_block(s, "block" + std::to_string(5 + i), PLANES[4 + i] + skip[i], PLANES[4 + i]);
     cur = PLANES[4 + i];
   }
-  s.convs.push_back({"final", "", 1, PLANES[7], 1});
+  s.convs.push_back({"final", "", 1, PLANES[7], out_channels});
   // blob layout: conv kernels, then BN (weight,bias,mean,var), then final.bias
   int64_t off = 0, ss = 0, wu = 0;
   for (auto &c : s.convs) {
@@ -100,16 +102,23 @@ NetSpec build_spec() {
     }
   }
   s.bias_off = off;
-  s.tensors.push_back({"final.bias", off, 1});
-  off += 1;
+  s.tensors.push_back({"final.bias", off, out_channels});
+  off += out_channels;
   s.numel = off;
   s.ss_numel = ss;
   s.wu_numel = wu;
   return s;
 }
 
-const NetSpec &spec() {
-  static const NetSpec s = build_spec();
-  return s;
+constexpr int MAX_HEAD = 8;  // `final` C_out supported by the head path (one 8-wide row of block8's output)
+
+// spec(1) is the SPS network; spec(k) differs only in final.kernel [8,k] / final.bias [k] (and the offsets after them)
+const NetSpec &spec(int out_channels = 1) {
+  static const std::vector<NetSpec> all = [] {
+    std::vector<NetSpec> v;
+    for (int k = 1; k <= MAX_HEAD; ++k) v.push_back(build_spec(k));
+    return v;
+  }();
+  return all[(size_t)(out_channels < 1 ? 1 : (out_channels > MAX_HEAD ? MAX_HEAD : out_channels)) - 1];
 }
 

@@ -170,15 +170,22 @@ struct sps_ctx {
   void *zero_region = nullptr;  // [counts (16 ints) | all tile masks]: one fill per forward
   size_t zero_bytes = 0;
   float final_bias = 0.f;
+  const NetSpec *net = nullptr;  // layout of the loaded weights: spec(out_channels)
+  // head path scratch (sps_forward_head): per-voxel feature sums / counts / means
+  long long *vacc = nullptr;
+  int *vcnt = nullptr;
+  float *vfeat = nullptr;
+  const float *cur_vfeat = nullptr;  // non-null while a forward with per-point features is being issued
+  bool cur_head = false;             // the forward being issued wants block8's output, not the fused `final`
   bool diag_have_state = false;
   float *slab = nullptr;     // split-K partial sums
   int64_t slab_stride = 0;
   // feature buffers
-  float *cat8 = nullptr, *b8t = nullptr, *b8r = nullptr, *b8o = nullptr, *logits = nullptr;
-  float *x1 = nullptr, *b1t = nullptr, *cat7 = nullptr, *b7t = nullptr, *b7r = nullptr, *b7o = nullptr;
-  float *x2 = nullptr, *b2t = nullptr, *b2r = nullptr, *cat6 = nullptr, *b6t = nullptr, *b6r = nullptr, *b6o = nullptr;
-  float *x3 = nullptr, *b3t = nullptr, *b3r = nullptr, *cat5 = nullptr, *b5t = nullptr, *b5r = nullptr, *b5o = nullptr;
-  float *x4 = nullptr, *b4t = nullptr, *b4r = nullptr, *b4o = nullptr;
+  float *cat8 = nullptr, *b8t = nullptr, *b8o = nullptr, *logits = nullptr;
+  float *x1 = nullptr, *b1t = nullptr, *cat7 = nullptr, *b7t = nullptr, *b7o = nullptr;
+  float *x2 = nullptr, *b2t = nullptr, *cat6 = nullptr, *b6t = nullptr, *b6o = nullptr;
+  float *x3 = nullptr, *b3t = nullptr, *cat5 = nullptr, *b5t = nullptr, *b5o = nullptr;
+  float *x4 = nullptr, *b4t = nullptr, *b4o = nullptr;
   // per-stage hipEvent profiling (sps_profile_*): off by default
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -301,32 +308,28 @@ int reserve(sps_ctx *c, int64_t n) {
   ALLOC(c->keep, int, cap);
   ALLOC(c->cat8, float, 16 * cap);
   ALLOC(c->b8t, float, 8 * cap);
-  ALLOC(c->b8r, float, 8 * cap);
   ALLOC(c->b8o, float, 8 * cap);
   ALLOC(c->logits, float, cap);
+  ALLOC(c->vacc, long long, cap);
+  ALLOC(c->vcnt, int, cap);
+  ALLOC(c->vfeat, float, cap);
   ALLOC(c->x1, float, 8 * cap);
   ALLOC(c->b1t, float, 8 * cap);
   ALLOC(c->cat7, float, 24 * cap);
   ALLOC(c->b7t, float, 16 * cap);
-  ALLOC(c->b7r, float, 16 * cap);
   ALLOC(c->b7o, float, 16 * cap);
   ALLOC(c->x2, float, 8 * cap);
   ALLOC(c->b2t, float, 16 * cap);
-  ALLOC(c->b2r, float, 16 * cap);
   ALLOC(c->cat6, float, 48 * cap);
   ALLOC(c->b6t, float, 32 * cap);
-  ALLOC(c->b6r, float, 32 * cap);
   ALLOC(c->b6o, float, 32 * cap);
   ALLOC(c->x3, float, 16 * cap);
   ALLOC(c->b3t, float, 32 * cap);
-  ALLOC(c->b3r, float, 32 * cap);
   ALLOC(c->cat5, float, 96 * cap);
   ALLOC(c->b5t, float, 64 * cap);
-  ALLOC(c->b5r, float, 64 * cap);
   ALLOC(c->b5o, float, 64 * cap);
   ALLOC(c->x4, float, 32 * cap);
   ALLOC(c->b4t, float, 64 * cap);
-  ALLOC(c->b4r, float, 64 * cap);
   ALLOC(c->b4o, float, 64 * cap);
   c->cap = cap;
   c->hcap = hcap;
@@ -414,7 +417,7 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
 }
 
 int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
-  const NetSpec &s = spec();
+  const NetSpec &s = *c->net;
   const int ci = s.find_conv(cc.name);
   if (ci < 0) return fail(SPS_ERR_INVALID, "unknown conv %s", cc.name);
   const ConvSpec &cs = s.convs[ci];
@@ -467,6 +470,11 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->cap * 4u);
   a.tile_cap = (int)(c->cap / 16);
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
+    if (c->cur_vfeat) {
+      hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
+                         c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, c->cur_vfeat, a.out, a.ldo);
+      return SPS_OK;
+    }
     hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
                        c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
     return SPS_OK;
@@ -585,7 +593,8 @@ int sps_ctx_create(int device, sps_ctx **out) {
   HIP_TRY(hipSetDevice(device));
   sps_ctx *c = new sps_ctx();
   c->device = device;
-  const NetSpec &s = spec();
+  const NetSpec &s = spec(MAX_HEAD);  // the widest head: every spec(k) fits
+  c->net = &spec(1);
   HIP_TRY(hipMalloc((void **)&c->err, sizeof(int)));
   HIP_TRY(hipMalloc((void **)&c->macc, 32 * 8 * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&c->pairs, 128 * sizeof(unsigned long long)));
@@ -637,8 +646,35 @@ int sps_weights_tensor_info(int idx, char *name, int name_cap, int64_t *offset, 
 
 int64_t sps_weights_numel(void) { return spec().numel; }
 
-int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) {
-  const NetSpec &s = spec();
+int sps_head_num_tensors(int out_channels) {
+  if (out_channels < 1 || out_channels > MAX_HEAD) return fail(SPS_ERR_INVALID, "out_channels must be in [1,%d]", MAX_HEAD);
+  return (int)spec(out_channels).tensors.size();
+}
+
+int sps_head_tensor_info(int out_channels, int idx, char *name, int name_cap, int64_t *offset, int64_t *numel) {
+  if (out_channels < 1 || out_channels > MAX_HEAD) return fail(SPS_ERR_INVALID, "out_channels must be in [1,%d]", MAX_HEAD);
+  const NetSpec &s = spec(out_channels);
+  if (idx < 0 || idx >= (int)s.tensors.size()) return fail(SPS_ERR_INVALID, "tensor index %d out of range", idx);
+  const TensorInfo &t = s.tensors[idx];
+  if (name && name_cap > 0) {
+    std::strncpy(name, t.name.c_str(), (size_t)name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  if (offset) *offset = t.off;
+  if (numel) *numel = t.numel;
+  return SPS_OK;
+}
+
+int64_t sps_head_numel(int out_channels) {
+  if (out_channels < 1 || out_channels > MAX_HEAD) return fail(SPS_ERR_INVALID, "out_channels must be in [1,%d]", MAX_HEAD);
+  return spec(out_channels).numel;
+}
+
+int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) { return sps_weights_load_head(c, blob, numel, 1); }
+
+int sps_weights_load_head(sps_ctx *c, const float *blob, int64_t numel, int out_channels) {
+  if (out_channels < 1 || out_channels > MAX_HEAD) return fail(SPS_ERR_INVALID, "out_channels must be in [1,%d]", MAX_HEAD);
+  const NetSpec &s = spec(out_channels);
   if (!c || !blob) return fail(SPS_ERR_INVALID, "null argument");
   if (numel != s.numel) return fail(SPS_ERR_INVALID, "blob has %lld floats, expected %lld", (long long)numel, (long long)s.numel);
   HIP_TRY(hipSetDevice(c->device));
@@ -694,6 +730,8 @@ int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) {
     }
   }
   c->final_bias = blob[s.bias_off];
+  c->net = &s;
+  HIP_TRY(hipDeviceSynchronize());  // forwards in flight on any stream still read the old weights
   HIP_TRY(hipMemcpy(c->wu, wu.data(), wu.size() * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->blob, blob, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -701,7 +739,41 @@ int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) {
   return SPS_OK;
 }
 
+// what the caller wants out of one forward: the SPS scores (head == false: `final` fused into
+// block8.conv2, slice + sigmoid) or the head path (per-point features in, [n, out_channels] out)
+struct ForwardOpts {
+  bool head = false;
+  const float *feats = nullptr;  // [n] per-point input feature; null = the constant 0.5 (models.py:22)
+  float t_base = 0.f;
+  int64_t ldo = 1;
+  int act = 0;                   // 0 = raw logits, 1 = sigmoid
+};
+
+static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
+                        const ForwardOpts &fo, void *stream);
+
 int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores, void *stream) {
+  if (c && c->have_weights && c->net->out_channels != 1)
+    return fail(SPS_ERR_INVALID, "the loaded weights have a %d-channel head: use sps_forward_head", c->net->out_channels);
+  return forward_impl(c, coords, ld, n, vs, scores, ForwardOpts{}, stream);
+}
+
+int sps_forward_head(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, const float *feats, float t_base,
+                     float *out, int64_t ldo, int activation, void *stream) {
+  if (c && c->have_weights && ldo < c->net->out_channels) return fail(SPS_ERR_INVALID, "ldo is smaller than out_channels");
+  if (activation != 0 && activation != 1) return fail(SPS_ERR_INVALID, "activation must be 0 (none) or 1 (sigmoid)");
+  if (!(t_base == floorf(t_base)) || fabsf(t_base) > 16777216.f) return fail(SPS_ERR_INVALID, "t_base must be an integer");
+  ForwardOpts fo;
+  fo.head = true;
+  fo.feats = feats;
+  fo.t_base = t_base;
+  fo.ldo = ldo;
+  fo.act = activation;
+  return forward_impl(c, coords, ld, n, vs, out, fo, stream);
+}
+
+static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
+                        const ForwardOpts &fo, void *stream) {
   if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
   if (!c->have_weights) return fail(SPS_ERR_NOWEIGHTS, "sps_weights_load has not been called");
   if (n < 0 || ld < 5 || (n > 0 && (!coords || !scores))) return fail(SPS_ERR_INVALID, "bad arguments");
@@ -744,12 +816,19 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   const unsigned gp = (unsigned)((n + 255) / 256);
   const unsigned gs0 = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   const unsigned gsb = (unsigned)(cap / SCAN_BLOCK);  // bound for scans over blocks
-  hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, L0.h, L0.sslot, L0.sbit,
+  hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, fo.t_base, L0.h, L0.sslot, L0.sbit,
                      c->err);
   hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   hipLaunchKernelGGL(k_points_rows, dim3(gp), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
                      L0.vblock, L0.vbit);
+  if (fo.feats) {  // voxel feature = mean of its points' features (App. A.4)
+    HIP_TRY(hipMemsetAsync(c->vacc, 0, (size_t)n * sizeof(long long), st));  // V <= n rows are used
+    HIP_TRY(hipMemsetAsync(c->vcnt, 0, (size_t)n * sizeof(int), st));
+    hipLaunchKernelGGL(k_voxel_feat_accum, dim3(gp), dim3(256), 0, st, fo.feats, L0.inv, (int)n, c->vacc, c->vcnt);
+    hipLaunchKernelGGL(k_voxel_feat_mean, dim3((unsigned)grid_for(n, 256, 2048)), dim3(256), 0, st, c->counts, c->vacc,
+                       c->vcnt, c->vfeat);
+  }
   prof_mark(c, "voxelize", st);
   // ---- levels 1..4: every coarser level straight from the level-0 blocks, batched over levels
   const int gb = grid_for(cap >> 2, 256, 256);
@@ -794,6 +873,8 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   prof_mark(c, "maps", st);
   // ---- network (minkunet.py:161-219)
   Level *lv = c->lv;
+  c->cur_vfeat = fo.feats ? c->vfeat : nullptr;
+  const bool fuse_final = !fo.head;
   const ConvCall calls[] = {
       {"conv0p1s1", nullptr, 1, c->cat8 + 8, 16, Map{c->nbr5, c->tm5}, 0, nullptr, 0, 1},
       {"conv1p1s2", c->cat8 + 8, 16, c->x1, 8, Map{lv[1].down, lv[1].tmdown}, 1, nullptr, 0, 1},
@@ -819,7 +900,7 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
       {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1, c->cat7, 24},
       {"convtr7p2s2", c->b7o, 16, c->cat8, 16, Map{lv[1].up, lv[1].tmup}, 0, nullptr, 0, 1},
       {"block8.0.conv1", c->cat8, 16, c->b8t, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1},
-      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1, c->cat8, 16, true},
+      {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1, c->cat8, 16, fuse_final},
   };
   for (const ConvCall &cc : calls) {
     if (skip_convs) break;
@@ -827,8 +908,16 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
     if (rc != SPS_OK) return rc;
     prof_mark(c, cc.name, st);
   }
-  hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->logits, L0.inv, (int)n,
-                     scores);
+  c->cur_vfeat = nullptr;
+  if (fo.head) {
+    const NetSpec &s = *c->net;
+    const ConvSpec &fs = s.convs[s.find_conv("final")];
+    hipLaunchKernelGGL(k_slice_head, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->b8o, 8, L0.inv, (int)n,
+                       c->blob + fs.w_off, c->blob + s.bias_off, s.out_channels, fo.act, scores, fo.ldo);
+  } else {
+    hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->logits, L0.inv, (int)n,
+                       scores);
+  }
   prof_mark(c, "slice_sigmoid", st);
   if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(grid_for(cap >> 2, 256, 256), NLV), dim3(256), 0, st, pa);
   prof_mark(c, "cleanup", st);

@@ -71,10 +71,12 @@ class BasicBlockParams(nn.Module):
 class CustomMinkUNet(nn.Module):
     def __init__(self, in_channels: int = 1, out_channels: int = 1, D: int = 4):
         super().__init__()
-        if (in_channels, out_channels, D) != (1, 1, 4):
-            raise NotImplementedError("the MI355X path implements the SPS instantiation "
-                                      "CustomMinkUNet(in_channels=1, out_channels=1, D=4) (models.py:17)")
+        if in_channels != 1 or D != 4 or not 1 <= out_channels <= 8:
+            raise NotImplementedError("the MI355X path implements CustomMinkUNet(in_channels=1, out_channels<=8, D=4): "
+                                      "SPS / MapMOS (out_channels=1, models.py:17, mapmos.py:36) and 4DMOS "
+                                      "(out_channels=3, mos4d.py:15)")
         self.D = D
+        self.out_channels = out_channels
         self.inplanes = INIT_DIM
         self.conv0p1s1 = SparseConvParams(125, in_channels, self.inplanes)
         self.bn0 = BatchNormParams(self.inplanes)

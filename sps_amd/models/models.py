@@ -49,14 +49,12 @@ def _require_device_tensor(t: torch.Tensor, what: str) -> None:
                            "is HIP-only and has no CPU fallback")
 
 
-class SPSModel(nn.Module):
-    def __init__(self, voxel_size: float):
-        super().__init__()
-        self.voxel_size = float(voxel_size)
-        # kept for API compatibility with models.py:16 (a plain attribute, not saved)
-        self.quantization = torch.Tensor([1.0, voxel_size, voxel_size, voxel_size, 1.0])
-        self.MinkUNet = CustomMinkUNet(in_channels=1, out_channels=1, D=4)
-        self.sigmoid = nn.Sigmoid()
+class NativeBackboneModule(nn.Module):
+    """Common part of the modules that own a ``self.MinkUNet`` parameter container and run it through
+    libsps_hip.so: keeps the native weight blob of a (device, stream) context in sync with the parameters."""
+
+    def _init_backbone(self, out_channels: int) -> None:
+        self.MinkUNet = CustomMinkUNet(in_channels=1, out_channels=out_channels, D=4)
         self._loaded_ctxs = set()        # native contexts that currently hold this module's weights
         # any load_state_dict that reaches the backbone (predict.py:58 or util.py:39) re-uploads
         self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self.mark_weights_dirty())
@@ -74,20 +72,20 @@ class SPSModel(nn.Module):
         owner = getattr(ctx, "weights_owner", None)
         if id(ctx) in self._loaded_ctxs and owner is not None and owner() is self:
             return                       # this module's weights are the ones resident in ctx
+        oc = self.MinkUNet.out_channels
         sd = self.MinkUNet.state_dict()
-        blob = np.empty(_native.lib.sps_weights_numel(), dtype=np.float32)
-        for name, off, numel in _native.weight_layout():
+        blob = np.empty(_native.lib.sps_head_numel(oc), dtype=np.float32)
+        for name, off, numel in _native.weight_layout(oc):
             t = sd[name].detach().to("cpu", torch.float32).contiguous().reshape(-1)
             if t.numel() != numel:
                 raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
             blob[off: off + numel] = t.numpy()
-        ctx.load_weights(blob.ctypes.data, blob.size)
+        ctx.load_weights(blob.ctypes.data, blob.size, oc)
         ctx.weights_owner = weakref.ref(self)   # a context is shared by every model on its device/stream
         self._loaded_ctxs.add(id(ctx))
 
-    # ---- forward --------------------------------------------------------------------------
-    def forward(self, coordinates: torch.Tensor) -> torch.Tensor:
-        """coordinates: float32 [N, >=5] rows (b, x, y, z, t); returns scores float32 [N]."""
+    @staticmethod
+    def _prepare_coordinates(coordinates: torch.Tensor) -> torch.Tensor:
         _require_device_tensor(coordinates, "coordinates")
         if coordinates.dim() != 2 or coordinates.shape[1] < 5:
             raise ValueError(f"coordinates must be [N, 5], got {tuple(coordinates.shape)}")
@@ -95,6 +93,22 @@ class SPSModel(nn.Module):
             coordinates = coordinates.to(torch.float32)
         if coordinates.stride(1) != 1:
             coordinates = coordinates.contiguous()
+        return coordinates
+
+
+class SPSModel(NativeBackboneModule):
+    def __init__(self, voxel_size: float):
+        super().__init__()
+        self.voxel_size = float(voxel_size)
+        # kept for API compatibility with models.py:16 (a plain attribute, not saved)
+        self.quantization = torch.Tensor([1.0, voxel_size, voxel_size, voxel_size, 1.0])
+        self._init_backbone(out_channels=1)
+        self.sigmoid = nn.Sigmoid()
+
+    # ---- forward --------------------------------------------------------------------------
+    def forward(self, coordinates: torch.Tensor) -> torch.Tensor:
+        """coordinates: float32 [N, >=5] rows (b, x, y, z, t); returns scores float32 [N]."""
+        coordinates = self._prepare_coordinates(coordinates)
         with torch.cuda.device(coordinates.device):
             stream = torch.cuda.current_stream().cuda_stream
             ctx = get_context(coordinates.device.index or 0, stream)
