@@ -81,17 +81,17 @@ class MapMOSNet(_HeadModule):
         self._init_backbone(out_channels=1)
 
     def predict(self, scan_input, map_input, scan_indices, map_indices):
-        def extend(tensor, batch_idx, time_idx):
-            ones = torch.ones(len(tensor), 1).type_as(tensor)
-            return torch.hstack([batch_idx * ones, tensor, time_idx * ones])
-
-        scan_input = extend(scan_input, 0, 0)                          # [batch_idx, x, y, z, t]
-        map_input = extend(map_input, 0, -1)
-        coordinates = torch.vstack([scan_input.reshape(-1, 5), map_input.reshape(-1, 5)])
-        indices = torch.vstack([scan_indices.reshape(-1, 1), map_indices.reshape(-1, 1)])
+        # [batch_idx = 0, x, y, z, t] with t = 0 for the scan and -1 for the map (mapmos.py:39-47), written
+        # straight into one buffer; scan rows come first, so the reference's `t == 0` mask is a prefix
+        scan_input, map_input = scan_input.reshape(-1, 3), map_input.reshape(-1, 3)
+        ns, nm = scan_input.shape[0], map_input.shape[0]
+        coordinates = torch.zeros((ns + nm, 5), dtype=scan_input.dtype, device=scan_input.device)
+        coordinates[:ns, 1:4] = scan_input
+        coordinates[ns:, 1:4] = map_input
+        coordinates[ns:, 4] = -1
+        indices = torch.cat([scan_indices.reshape(-1, 1), map_indices.reshape(-1, 1)])
         logits = self.forward(coordinates, indices)
-        mask_scan = coordinates[:, 4] == 0.0
-        return logits[mask_scan], logits[~mask_scan]
+        return logits[:ns], logits[ns:]
 
     def forward(self, coordinates: torch.Tensor, indices: torch.Tensor) -> torch.Tensor:
         # normalise indices (mapmos.py:65-71); the division by the voxel size happens in the native quantiser
