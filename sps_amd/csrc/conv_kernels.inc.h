@@ -25,6 +25,7 @@ struct ConvArgs {
   float in_const;  // conv0: the constant input feature (0.5, models.py:22)
   uint32_t in_bytes, wu_bytes, nbr_bytes;  // extents of `in` / `Wu` / `nbr` for the buffer descriptors
   int tile_cap;                            // tiles the tmask buffer holds (cap / 16)
+  int trace_on;                            // SPS_WAVE_TRACE builds: record this launch
   // fused 1x1 "downsample" branch of a BasicBlock (resnet.py:98-108): upk2 extra units read from in2 at
   // the output row itself, weights stored after the K*upk regular units (pre-scaled, see permute)
   const float *in2;
@@ -62,8 +63,22 @@ constexpr int KCHUNK = 32;
 constexpr uint32_t OOR = 0xFFFF0000u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+#ifndef SPS_A_QUAD
+#define SPS_A_QUAD 0
+#endif
+
+#if defined(SPS_WAVE_TRACE)
+// DIAGNOSTIC build only (tools/wave_trace.py): per-wave wall-clock stamps (100 MHz) of one chosen layer
+__device__ unsigned long long g_wave_trace[4 * 32768];
+#endif
+
 template <int NTW, int G, int MINW, bool DS, bool FIN>
 __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
+#if defined(SPS_WAVE_TRACE)
+  const unsigned long long tr_t0 = wall_clock64();
+  unsigned long long tr_t1 = 0;
+  int tr_tiles = 0, tr_units = 0;
+#endif
   __shared__ unsigned char klist[4][128];
   __shared__ uint32_t aoff_s[4][KCHUNK * 16];
   __shared__ uint32_t woff_s[4][KCHUNK];
@@ -130,6 +145,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
     per = (per + 3) & ~3;
     const int j0 = split * per;
     const int j1 = min(U, j0 + per);
+#if defined(SPS_WAVE_TRACE)
+    if (tr_tiles == 0) tr_t1 = wall_clock64();
+    ++tr_tiles;
+    tr_units += U;
+#endif
 
     floatx4 acc[NTW];
 #pragma unroll
@@ -177,6 +197,14 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       int kk = (int)(((float)jl + 0.5f) * a.inv_upk);
       int c4 = jl - kk * upk;
       kk -= kc;
+#if SPS_A_QUAD
+      // A is FETCHED quad-contiguous: lane L = 4*rho + qa reads unit (4i + qa) of row rho, so the four
+      // lanes of a quad read up to 64 contiguous bytes of ONE row (one TCP request; in the MFMA layout
+      // lane = r + 16 q the quad's pieces lie in four different rows and cost 2-3 TA cycles per quad:
+      // tools/microbench/l1_gather.hip), then 4 ds_bpermute move the pieces to lane r + 16 q.
+      const int asrc = ((lane >> 2) + 16 * (lane & 3)) * 4;  // lane holding the offset of (row rho, unit qa)
+      const int xsrc = (4 * r + q) * 4;  // bpermute byte address of the lane that fetched (row r, unit q)
+#endif
       for (int jb = ju0; jb < ju1; jb += 4 * G) {
         u32x4 va[G];
         u32x4 vb[G][NTW];
@@ -187,6 +215,9 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 #if defined(SPS_ABLATE_A)
           const uint32_t oa = OOR;
           (void)ao;
+#elif SPS_A_QUAD
+          const uint32_t oa = (uint32_t)__builtin_amdgcn_ds_bpermute(
+              asrc, (int)(valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR));
 #else
           const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
 #endif
@@ -204,6 +235,15 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
           c4 -= wrap ? upk : 0;
           kk += wrap;
         }
+#if SPS_A_QUAD && !defined(SPS_ABLATE_A)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          va[g].x = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].x);
+          va[g].y = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].y);
+          va[g].z = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].z);
+          va[g].w = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].w);
+        }
+#endif
 #if defined(SPS_ABLATE_MFMA)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -303,6 +343,17 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       }
     }
   }
+#if defined(SPS_WAVE_TRACE)
+  if (a.trace_on && lane == 0) {
+    const int w = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave;
+    if (w < 32768) {
+      g_wave_trace[4 * w + 0] = tr_t0;
+      g_wave_trace[4 * w + 1] = tr_t1;
+      g_wave_trace[4 * w + 2] = wall_clock64();
+      g_wave_trace[4 * w + 3] = ((unsigned long long)tr_tiles << 32) | (unsigned)tr_units;
+    }
+  }
+#endif
 }
 
 // conv0p1s1 (5x5x5x1, 1 -> 8, minkunet.py:55-62) fused with its kernel map.  The input feature is

@@ -469,6 +469,10 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
   a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->cap * 4u);
   a.tile_cap = (int)(c->cap / 16);
+  {
+    static const char *trace_layer = getenv("SPS_TRACE_LAYER");  // diagnostic builds (-DSPS_WAVE_TRACE) only
+    a.trace_on = trace_layer && std::strcmp(trace_layer, cc.name) == 0;
+  }
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
     if (c->cur_vfeat) {
       hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
@@ -1251,6 +1255,15 @@ int sps_get_logits(sps_ctx *c, float *logits_dev) {
   HIP_TRY(hipMemcpy(logits_dev, c->logits, (size_t)cnt[0] * sizeof(float), hipMemcpyDeviceToDevice));
   return SPS_OK;
 }
+
+#if defined(SPS_WAVE_TRACE)
+// diagnostic builds only; not part of include/sps_hip.h
+int sps_debug_wave_trace(unsigned long long *host, int n_waves) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_trace), (size_t)n_waves * 4 * sizeof(unsigned long long)));
+  return SPS_OK;
+}
+#endif
 
 int sps_get_feature(sps_ctx *c, const char *name, float *out_dev, int64_t *rows, int64_t *cols) {
   if (!c || !name || !rows || !cols) return fail(SPS_ERR_INVALID, "null argument");

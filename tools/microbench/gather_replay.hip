@@ -1,0 +1,121 @@
+// Replays the A-operand gathers of a 3x3x3x3 layer with a REAL neighbour table (dumped by
+// tools/microbench/dump_nbr.py) in two feature layouts:
+//   row-major [V][C]        : lane (r, q) reads 16 B at  v * C*4 + q*16         (what k_conv does today)
+//   planar    [C/4][V][4]   : lane (r, q) reads 16 B at  q * plane + v * 16
+// r = lane & 15 is the MFMA row, q = lane >> 4 the channel quad (C = 16).  Staging of the neighbour rows
+// through LDS is identical in both (and timed alone as "stage only").
+//   hipcc --offload-arch=gfx950 -O3 -o gather_replay gather_replay.hip && ./gather_replay /tmp/nbr.bin
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+template <int MODE>  // 0 stage only, 1 row-major, 2 planar
+__global__ __launch_bounds__(256, 8) void k_replay(const int *__restrict__ nbr, const uint32_t *__restrict__ tmask, int V, int64_t ldn,
+                                                   const char *__restrict__ feat, uint32_t feat_bytes, uint32_t plane_bytes, int C,
+                                                   float *out) {
+  __shared__ uint32_t rows_s[4][81 * 16];
+  __shared__ unsigned char kl_s[4][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int ntiles = (V + 15) >> 4;
+  uint32_t *rs = rows_s[wave];
+  unsigned char *kl = kl_s[wave];
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)feat, 0, (int)feat_bytes, 0x00020000);
+  float4 acc = {0, 0, 0, 0};
+  const int upk = C / 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+    const uint32_t *m = tmask + (size_t)tile * 4;
+    const uint32_t w0 = m[lane >> 5], w1 = m[2 + (lane >> 5)];
+    const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = lane + 64 < 81 && ((w1 >> (lane & 31)) & 1u);
+    const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int n0 = __popcll(bal0);
+    __builtin_amdgcn_wave_barrier();
+    if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)lane;
+    if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(lane + 64);
+    const int nk = n0 + __popcll(bal1);
+    __builtin_amdgcn_wave_barrier();
+    // stage: 4 offsets per pass (lane group q takes offset j + q)
+    for (int j = 0; j < nk; j += 4) {
+      const int jj = j + q;
+      if (jj < nk) {
+        const int k = kl[jj];
+        const int u = row0 + r;
+        const int v = u < V ? nbr[(size_t)k * ldn + u] : -1;
+        rs[jj * 16 + r] = v < 0 ? 0xFFFFFFFFu : (MODE == 2 ? (uint32_t)v * 16u : (uint32_t)v * (uint32_t)(C * 4));
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (MODE == 0) {
+      acc.x += (float)rs[(nk - 1) * 16 + r];
+      continue;
+    }
+    // units u = j * upk + c4 ; lane group q handles unit 4i + q
+    const int U = nk * upk;
+    for (int i = 0; i < U; i += 16) {   // 4 independent wave-loads in flight per wave
+      float4 v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int unit = i + 4 * e + q;
+        const int j = unit / upk, c4 = unit - j * upk;
+        uint32_t off = rs[min(j, nk - 1) * 16 + r];
+        off = unit < U ? off : 0xFFFFFFFFu;
+        const uint32_t add = MODE == 2 ? (uint32_t)c4 * plane_bytes : (uint32_t)c4 * 16u;
+        off = __builtin_elementwise_add_sat(off, add);
+        v[e] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsF, off, 0, 0));
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc.x += v[e].x; acc.y += v[e].y; acc.z += v[e].z; acc.w += v[e].w; }
+    }
+  }
+  if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = acc.x;
+}
+
+int main(int argc, char **argv) {
+  FILE *f = fopen(argc > 1 ? argv[1] : "/tmp/nbr.bin", "rb");
+  if (!f) { printf("no input\n"); return 1; }
+  int64_t hdr[3];
+  if (fread(hdr, 8, 3, f) != 3) return 1;
+  const int64_t V = hdr[0], ldn = hdr[1], ntiles = hdr[2];
+  std::vector<int> nbr((size_t)81 * ldn);
+  std::vector<uint32_t> tm((size_t)ntiles * 4);
+  if (fread(nbr.data(), 4, nbr.size(), f) != nbr.size()) return 1;
+  if (fread(tm.data(), 4, tm.size(), f) != tm.size()) return 1;
+  fclose(f);
+  int *dn; uint32_t *dm; char *feat; float *out;
+  CHECK(hipMalloc(&dn, nbr.size() * 4));
+  CHECK(hipMalloc(&dm, tm.size() * 4));
+  CHECK(hipMemcpy(dn, nbr.data(), nbr.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(dm, tm.data(), tm.size() * 4, hipMemcpyHostToDevice));
+  CHECK(hipMalloc(&out, 64));
+  hipEvent_t a, b;
+  CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+  printf("V = %lld rows, %lld tiles\n", (long long)V, (long long)ntiles);
+  for (int C : {8, 16, 32}) {
+    const size_t fbytes = (size_t)ldn * C * 4;
+    CHECK(hipMalloc(&feat, fbytes));
+    CHECK(hipMemset(feat, 0, fbytes));
+    const uint32_t plane = (uint32_t)(ldn * 16);
+    const int grid = (int)((ntiles + 3) / 4);
+    float ms[3];
+    for (int mode = 0; mode < 3; ++mode) {
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipEventRecord(a));
+        if (mode == 0) hipLaunchKernelGGL((k_replay<0>), dim3(grid), dim3(256), 0, 0, dn, dm, (int)V, ldn, feat, (uint32_t)fbytes, plane, C, out);
+        if (mode == 1) hipLaunchKernelGGL((k_replay<1>), dim3(grid), dim3(256), 0, 0, dn, dm, (int)V, ldn, feat, (uint32_t)fbytes, plane, C, out);
+        if (mode == 2) hipLaunchKernelGGL((k_replay<2>), dim3(grid), dim3(256), 0, 0, dn, dm, (int)V, ldn, feat, (uint32_t)fbytes, plane, C, out);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        CHECK(hipEventElapsedTime(&ms[mode], a, b));
+      }
+    }
+    printf("C = %2d: stage only %.1f us, row-major %.1f us, planar %.1f us\n", C, ms[0] * 1e3, ms[1] * 1e3, ms[2] * 1e3);
+    CHECK(hipFree(feat));
+  }
+  return 0;
+}
