@@ -61,6 +61,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
+    ap.add_argument("--threads", type=int, default=1,
+                    help="host threads issuing the launches (each owns streams s = t mod threads)")
     ap.add_argument("--streams", type=int, default=16,
                     help="independent scans in flight per GPU (one HIP stream + native context each); 1 = strictly serial")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
@@ -119,7 +121,10 @@ def main():
             scores = net(batch)
             ctxs[i % S].metrics_dev(scores.data_ptr(), batch.data_ptr(), batch.stride(0), n_points, eps, 1,
                                     rows[i % max(K, 1)].data_ptr(), st.cuda_stream)
+        step_scores[0] = scores
         return scores
+
+    step_scores = [None]
 
     def barrier():
         if dist is not None:
@@ -134,8 +139,26 @@ def main():
     t0 = time.perf_counter()
     for st, e in zip(streams, ev0):
         e.record(st)
-    for i in range(K):
-        scores = step(i)
+    if args.threads > 1:
+        # several host threads issue the launches (ctypes releases the GIL inside libsps_hip.so): thread t owns
+        # the streams s = t mod T, so a stream is only ever touched by one thread
+        import threading
+        T = args.threads
+
+        def worker(t):
+            torch.cuda.set_device(dev)
+            for i in range(K):
+                if (i % S) % T == t:
+                    step(i)
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        scores = step_scores[0]
+    else:
+        for i in range(K):
+            scores = step(i)
     for st, e in zip(streams, ev1):
         e.record(st)
     gathered = None

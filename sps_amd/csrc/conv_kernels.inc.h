@@ -16,8 +16,7 @@ struct ConvArgs {
   const int *nbr;         // [K][ldn] or null (identity, K == 1)
   const uint32_t *tmask;  // [tiles][4] present-offset mask per 16-row tile, or null (K == 1)
   const int *n_out;       // device count of output rows
-  float *slab;            // split-K partial sums [S][slab_stride] (S > 1)
-  int64_t ldn, slab_stride;
+  int64_t ldn;
   int ldi, ldo, ldr;
   int K, cin, cout, NT, upk;
   int relu, S;
@@ -72,7 +71,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_wave_trace[4 * 32768];
 #endif
 
-template <int NTW, int G, int MINW, bool DS, bool FIN>
+template <int NTW, int G, int MINW, bool DS, bool FIN, int S>
 __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 #if defined(SPS_WAVE_TRACE)
   const unsigned long long tr_t0 = wall_clock64();
@@ -87,7 +86,12 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int nt0 = blockIdx.y * NTW;
-  const int split = blockIdx.z;
+  // split-K inside the workgroup: its four waves are (4 / S) tiles x S splits of the tile's unit list; the
+  // partial sums meet in LDS (fixed order -> deterministic), so there is no slab in HBM and no second launch
+  constexpr int tpw = 4 / S;                           // S = 1, 2 or 4; tiles per workgroup
+  const int tl = S == 1 ? wave : wave / S;
+  const int split = S == 1 ? 0 : wave - tl * S;
+  __shared__ float red_s[S > 1 ? 3 * NTW * 4 * 64 : 1];
   unsigned char *kl = klist[wave];
   uint32_t *ao = aoff_s[wave];
   uint32_t *wo = woff_s[wave];
@@ -111,20 +115,27 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const float efw = (FIN && r < a.cout) ? a.fin_w[r] : 0.f;
   // the first tile's mask words do not depend on the row count: fetch them alongside it (saves a
   // dependent round trip; tile_cap = tiles the mask buffer was allocated for)
-  const int tile_first = blockIdx.x * 4 + wave;
+  const int tile_first = blockIdx.x * tpw + tl;
   uint32_t pw0 = 0u, pw1 = 0u;
   if (a.tmask && tile_first < a.tile_cap) {
     pw0 = a.tmask[(size_t)tile_first * 4 + (lane >> 5)];
     pw1 = a.tmask[(size_t)tile_first * 4 + 2 + (lane >> 5)];
   }
-  for (int tile = tile_first; tile < ntiles; tile += gridDim.x * 4) {
+  // the loop bound is workgroup-uniform (the S > 1 path has barriers); a wave whose tile lies past the end
+  // runs an empty unit list
+  for (int grp = blockIdx.x; grp * tpw < ntiles; grp += gridDim.x) {
+    const int tile = grp * tpw + tl;
+    const bool active = tile < ntiles;
+    if (S == 1 && !active) continue;
     const int row0 = tile * 16;
     // ---- prologue: compact list of present offsets (wave-synchronous LDS)
     int nk = 1;
     __builtin_amdgcn_wave_barrier();
     if (a.tmask) {
       uint32_t w0 = pw0, w1 = pw1;
-      if (tile != tile_first) {
+      if (!active) {
+        w0 = w1 = 0u;
+      } else if (tile != tile_first) {
         const uint32_t *m = a.tmask + (size_t)tile * 4;
         w0 = m[lane >> 5];
         w1 = m[2 + (lane >> 5)];
@@ -140,8 +151,8 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       kl[0] = 0;
     }
     __builtin_amdgcn_wave_barrier();
-    const int U = nk * upk;
-    int per = (U + a.S - 1) / a.S;
+    const int U = active ? nk * upk : 0;
+    int per = (U + S - 1) / S;
     per = (per + 3) & ~3;
     const int j0 = split * per;
     const int j1 = min(U, j0 + per);
@@ -267,7 +278,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       }
     }
     // ---- fused residual branch: r = downsample(x) = x[row] @ Wds (identity map), last split only
-    if (DS && split == a.S - 1) {
+    if (DS && split == S - 1) {
       const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in2, 0, (int)a.in2_bytes, 0x00020000);
       const int row = row0 + r;
       const uint32_t rowoff = row < count ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) : OOR;
@@ -297,6 +308,26 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
         }
       }
     }
+    if constexpr (S > 1) {
+      __syncthreads();  // the previous group's reader is done with red_s
+      if (split != 0) {
+        float *rd = red_s + (tl * (S - 1) + split - 1) * (NTW * 4 * 64) + lane;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) rd[(nt * 4 + i) * 64] = acc[nt][i];
+      }
+      __syncthreads();
+      if (split != 0) continue;
+      for (int sp = 1; sp < S; ++sp) {  // s ascending, as the former reduce kernel summed the slabs
+        const float *rd = red_s + (tl * (S - 1) + sp - 1) * (NTW * 4 * 64) + lane;
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[nt][i] += rd[(nt * 4 + i) * 64];
+      }
+      if (!active) continue;
+    }
     // ---- epilogue.  C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
     if (NTW == 1 && FIN) {
       // block8.conv2 + `final`: the 8 channels of a row sit in lanes r = 0..7 of its 16-lane group
@@ -322,15 +353,6 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
     for (int nt = 0; nt < NTW; ++nt) {
       const int col = (nt0 + nt) * 16 + r;
       if (col >= a.cout) continue;
-      if (a.S > 1) {
-        float *sl = a.slab + (size_t)split * a.slab_stride;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int ro = row0 + q * 4 + i;
-          if (ro < count) sl[(size_t)ro * a.cout + col] = acc[nt][i];
-        }
-        continue;
-      }
       const float sc = esc[nt], sh = esh[nt];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   }
 #if defined(SPS_WAVE_TRACE)
   if (a.trace_on && lane == 0) {
-    const int w = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) * 4 + wave;
+    const int w = (blockIdx.x + gridDim.x * blockIdx.y) * 4 + wave;
     if (w < 32768) {
       g_wave_trace[4 * w + 0] = tr_t0;
       g_wave_trace[4 * w + 1] = tr_t1;
@@ -653,21 +675,6 @@ __global__ __launch_bounds__(256, MINW) void k_conv_sc(ConvArgs a) {
       }
     }
     __syncthreads();
-  }
-}
-
-// split-K tail: out = epilogue(sum_s slab[s]) with s ascending (deterministic).
-__global__ void k_reduce_epilogue(ConvArgs a) {
-  const int count = *a.n_out;
-  const int64_t total = (int64_t)count * a.cout;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int ro = (int)(i / a.cout), col = (int)(i - (int64_t)ro * a.cout);
-    float sum = 0.f;
-    for (int s = 0; s < a.S; ++s) sum += a.slab[(size_t)s * a.slab_stride + i];
-    float y = sum * a.scale[col] + a.shift[col];
-    if (a.res) y += a.res[(size_t)ro * a.ldr + col];
-    if (a.relu) y = fmaxf(y, 0.f);
-    a.out[(size_t)ro * a.ldo + col] = y;
   }
 }
 

@@ -84,6 +84,9 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_G4
 #define SPS_G4 2
 #endif
+#ifndef SPS_WS
+#define SPS_WS 6  // min waves/SIMD of the split-K instantiations (coarse levels: few waves anyway)
+#endif
 #ifndef SPS_W4
 #define SPS_W4 4
 #endif
@@ -98,7 +101,7 @@ int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_SPLIT = 8;
+constexpr int MAX_SPLIT = 4;  // split-K lives inside a 4-wave workgroup
 
 inline int64_t next_pow2(int64_t v) {
   int64_t p = 1;
@@ -178,8 +181,6 @@ struct sps_ctx {
   const float *cur_vfeat = nullptr;  // non-null while a forward with per-point features is being issued
   bool cur_head = false;             // the forward being issued wants block8's output, not the fused `final`
   bool diag_have_state = false;
-  float *slab = nullptr;     // split-K partial sums
-  int64_t slab_stride = 0;
   // feature buffers
   float *cat8 = nullptr, *b8t = nullptr, *b8o = nullptr, *logits = nullptr;
   float *x1 = nullptr, *b1t = nullptr, *cat7 = nullptr, *b7t = nullptr, *b7o = nullptr;
@@ -302,8 +303,6 @@ int reserve(sps_ctx *c, int64_t n) {
       }
     }
   }
-  c->slab_stride = cap * 64;
-  ALLOC(c->slab, float, (size_t)MAX_SPLIT * c->slab_stride);
   ALLOC(c->block_sums, int, 2 * (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
   ALLOC(c->keep, int, cap);
   ALLOC(c->cat8, float, 16 * cap);
@@ -411,7 +410,7 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   snprintf(name, sizeof name, "SPS_GEOM_L%d", level);
   if (const char *e = getenv(name)) {
     int full = 0, S = 1;
-    if (sscanf(e, "%d,%d", &full, &S) == 2 && S >= 1 && S <= MAX_SPLIT) g = {full ? nt : 1, S};
+    if (sscanf(e, "%d,%d", &full, &S) == 2 && (S == 1 || S == 2 || S == 4)) g = {full ? nt : 1, S};
   }
   return g;
 }
@@ -443,8 +442,6 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.inv_upk = cs.cin >= 4 ? 1.0f / (float)cs.upk() : 1.f;
   a.relu = cc.relu;
   a.in_const = 0.5f;  // models.py:22
-  a.slab = c->slab;
-  a.slab_stride = c->slab_stride;
   const Geometry g = conv_geometry(cc.level_out, cs.K, cs.cin, a.NT);
   a.S = g.S;
   // expected tiles at this level (rows shrink ~2.5x per level); floor keeps small clouds parallel
@@ -453,7 +450,8 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   if (gx > 4096) gx = 4096;
   static const int max_wg = [] { const char *e = getenv("SPS_CONV_MAX_WG"); return e ? atoi(e) : 0; }();
   if (max_wg > 0 && gx * (a.NT / g.ntw) * g.S > max_wg) gx = std::max<int64_t>(16, max_wg / ((a.NT / g.ntw) * g.S));
-  const dim3 grid((unsigned)gx, (unsigned)(a.NT / g.ntw), (unsigned)g.S);
+  // a workgroup holds 4 / S tiles x S splits: S times as many workgroups for the same tiles
+  const dim3 grid((unsigned)(gx * g.S), (unsigned)(a.NT / g.ntw), 1u);
   a.in2 = cc.in2;
   a.ldi2 = cc.ldi2;
   a.upk2 = cs.ds_cin / 4;
@@ -512,25 +510,35 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     return SPS_OK;
   }
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
-  if (g.ntw == 1) {
-    if (cc.fin)
-      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true>), grid, dim3(256), 0, st, a);
-    else if (ds)
-      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, false>), grid, dim3(256), 0, st, a);
+  if (g.S > 1 && g.ntw != 1) return fail(SPS_ERR_INVALID, "split-K needs one column tile per wave");
+  if (g.S == 4) {
+    if (ds)
+      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_WS, true, false, 4>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_W1, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_WS, false, false, 4>), grid, dim3(256), 0, st, a);
+  } else if (g.S == 2) {
+    if (ds)
+      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_WS, true, false, 2>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_WS, false, false, 2>), grid, dim3(256), 0, st, a);
+  } else if (g.ntw == 1) {
+    if (cc.fin)
+      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
+    else if (ds)
+      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, false, 1>), grid, dim3(256), 0, st, a);
+    else
+      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_W1, false, false, 1>), grid, dim3(256), 0, st, a);
   } else if (g.ntw == 2) {
     if (ds)
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, true, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, true, false, 1>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, false, false, 1>), grid, dim3(256), 0, st, a);
   } else {
     if (ds)
-      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, true, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, true, false, 1>), grid, dim3(256), 0, st, a);
     else
-      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, false, false>), grid, dim3(256), 0, st, a);
+      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, false, false, 1>), grid, dim3(256), 0, st, a);
   }
-  if (g.S > 1) hipLaunchKernelGGL(k_reduce_epilogue, dim3((unsigned)(gx < 256 ? gx : 256)), dim3(256), 0, st, a);
   return SPS_OK;
 }
 
