@@ -96,8 +96,12 @@ __device__ inline int wave_run_insert(const BHash &h, uint64_t key, bool ok, uin
 // the wave elects one lane per distinct block, which issues the three atomics for the whole group.
 __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restrict__ coords, int64_t ld, int n, float vs,
                                                            float t_base, BHash h, int *__restrict__ sslot,
-                                                           unsigned char *__restrict__ sbit, int *err) {
+                                                           unsigned char *__restrict__ sbit, int *err,
+                                                           uint4 *__restrict__ zero_region, int zero_vec4) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  // first kernel of the forward: clears the counters and every tile mask of the previous forward (they stay
+  // readable by the introspection getters until then) -- no separate fill launch
+  for (int i = p; i < zero_vec4; i += gridDim.x * blockDim.x) zero_region[i] = make_uint4(0u, 0u, 0u, 0u);
   bool ok = false;
   uint64_t key = KEY_EMPTY;
   int bit = 0;
@@ -151,11 +155,10 @@ struct PyramidArgs {
 // level (App. A.9: floor(c / 2ts) * 2ts applied l times = a right shift of the biased coordinate).
 // A level-0 block covers 2x2x2 level-1 voxels (an octant of its parent block) and exactly one voxel
 // of levels 2..4.
-__global__ __launch_bounds__(256) void k_blocks_to_ancestors(PyramidArgs a) {
+__device__ inline void blocks_to_ancestors(const PyramidArgs &a, int l, int bx, int nbx) {
   const int n = a.counts[8];
-  const int l = 1 + (int)blockIdx.y;
   const int nround = (n + 255) & ~255;  // whole waves enter wave_run_insert
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < nround; r += gridDim.x * blockDim.x) {
+  for (int r = bx * 256 + (int)threadIdx.x; r < nround; r += nbx * 256) {
     const bool ok = r < n;
     uint64_t pkey = KEY_EMPTY;
     unsigned long long pm = 0;
@@ -293,9 +296,17 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv
 
 // point -> voxel row (inverse map of TensorField.sparse / slice, models.py:25,28); also records the
 // (block, bit) of every level-0 row (all points of a voxel write the same values).
-__global__ void k_points_rows(const int *__restrict__ sslot, const unsigned char *__restrict__ sbit, int n, BHash h,
-                              const int *__restrict__ bbase, int *__restrict__ inv, int *__restrict__ vblock,
-                              unsigned char *__restrict__ vbit) {
+// Launched together with blocks_to_ancestors (both only need the level-0 block ranks): workgroups
+// [0, gp) map points to rows, the next 4 * gb insert the ancestor blocks of levels 1..4.
+__global__ __launch_bounds__(256) void k_rows_ancestors(const int *__restrict__ sslot, const unsigned char *__restrict__ sbit,
+                                                         int n, BHash h, const int *__restrict__ bbase,
+                                                         int *__restrict__ inv, int *__restrict__ vblock,
+                                                         unsigned char *__restrict__ vbit, PyramidArgs a, int gp, int gb) {
+  if ((int)blockIdx.x >= gp) {
+    const int b = (int)blockIdx.x - gp;
+    blocks_to_ancestors(a, 1 + b / gb, b % gb, gb);
+    return;
+  }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
   const int s = sslot[p];
@@ -313,10 +324,9 @@ __global__ void k_points_rows(const int *__restrict__ sslot, const unsigned char
 // blockIdx.y = l in 0..3.  (a) parent / child block links between level l and l+1 (one hash probe per
 // block); (b) for l = 0 only, one thread per level-0 block also writes the (block, bit) of the rows it
 // covers at every coarser level (each coarse voxel is covered by at least one level-0 block).
-__global__ void k_link_levels(PyramidArgs a) {
-  const int l = blockIdx.y;
+__device__ inline void link_levels(const PyramidArgs &a, int l, int bx, int nbx) {
   const int n = a.counts[8 + l];
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+  for (int r = bx * 256 + (int)threadIdx.x; r < n; r += nbx * 256) {
     const uint64_t key = a.bkey[l][r];
     const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF),
                    bz = (uint32_t)((key >> 36) & 0x3FFFF);
@@ -363,9 +373,14 @@ __global__ void k_link_levels(PyramidArgs a) {
 // adjacency of blocks (blockIdx.y = level): badj[r][a] = rank of the block at offset (dbx,dby,dbz,dt)
 // in {-1,0,1}^4, a = (dbx+1) + 3(dby+1) + 9(dbz+1) + 27(dt+1), or -1.  The only hash probes of the
 // kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
-__global__ void k_block_adj(PyramidArgs a, int c1, int c2, int c3, int c4, int c5) {
+// One launch with link_levels (both only need the block ranks of all levels): workgroups [0, 4 * gb) link.
+__global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1, int c2, int c3, int c4, int c5) {
+  if ((int)blockIdx.x < 4 * gb) {
+    link_levels(a, (int)blockIdx.x / gb, (int)blockIdx.x % gb, gb);
+    return;
+  }
   // workgroup -> (level, chunk): chunk offsets 0, c1, c2, c3, c4, c5 (expected sizes, grid-stride beyond)
-  const int bx = (int)blockIdx.x;
+  const int bx = (int)blockIdx.x - 4 * gb;
   const int level = bx < c1 ? 0 : bx < c2 ? 1 : bx < c3 ? 2 : bx < c4 ? 3 : 4;
   const int lo = level == 0 ? 0 : level == 1 ? c1 : level == 2 ? c2 : level == 3 ? c3 : c4;
   const int hi = level == 0 ? c1 : level == 1 ? c2 : level == 2 ? c3 : level == 3 ? c4 : c5;
@@ -389,11 +404,10 @@ __global__ void k_block_adj(PyramidArgs a, int c1, int c2, int c3, int c4, int c
 }
 
 // hash slots used by this forward go back to "free" (the tables are never memset per scan).
-__global__ void k_bhash_cleanup(PyramidArgs a) {
-  const int l = blockIdx.y;
+__device__ inline void bhash_cleanup(const PyramidArgs &a, int l, int bx, int nbx) {
   const int n = a.counts[8 + l];
   const BHash h = a.h[l];
-  for (int r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+  for (int r = bx * 256 + (int)threadIdx.x; r < n; r += nbx * 256) {
     const int s = a.bslot[l][r];
     h.keys[s] = KEY_EMPTY;
     h.mask[s] = 0ull;

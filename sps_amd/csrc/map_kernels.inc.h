@@ -41,10 +41,10 @@ struct MapsArgs {
   int64_t ldn;
 };
 
-__device__ inline int level_of_chunk(const MapsArgs &a, int first_level, int &local) {
+__device__ inline int level_of_chunk(const MapsArgs &a, int first_level, int &local, int bid) {
   int l = first_level;
-  while (l + 1 < NLV && (int)blockIdx.x >= a.chunk_off[l + 1]) ++l;
-  local = (int)blockIdx.x - a.chunk_off[l];
+  while (l + 1 < NLV && bid >= a.chunk_off[l + 1]) ++l;
+  local = bid - a.chunk_off[l];
   return l;
 }
 
@@ -83,12 +83,11 @@ __device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int
 // nbr[k*ldn + u] = row of the voxel at (coordinate of u) + offset_k, or -1   (App. A.6-A.8)
 //   3x3x3x3 (all levels): k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1); blockIdx.y = (dy,dz,dt) combo
 // offsets are in units of the level's stride (the block grid already is).
-__global__ __launch_bounds__(256) void k_build_nbr3(MapsArgs a) {
+__device__ inline void build_nbr3(const MapsArgs &a, int bid, int c) {
   int local;
-  const int l = level_of_chunk(a, 0, local);
+  const int l = level_of_chunk(a, 0, local, bid);
   const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
   const int n = a.counts[l];
-  const int c = blockIdx.y;  // 0..26
   const int dy = c % 3 - 1, dz = (c / 3) % 3 - 1, dt = c / 9 - 1;
   const LevelView L = a.L[l];
   for (int u = local * 256 + threadIdx.x; u < n; u += nchunks * 256)
@@ -110,9 +109,9 @@ __global__ __launch_bounds__(256) void k_build_nbr5(const int *__restrict__ n_ou
 //  down (App. A.9):  out = coarse voxel u, children at u + {0,1}^3 (fine units), k = dx + 2dy + 4dz
 //  up   (App. A.10): fine voxel v receives exactly one term, from its parent, through offset
 //                    k = position of v inside the parent: up[k*ldn + v] = (k == oct(v)) ? parent : -1
-__global__ __launch_bounds__(256) void k_build_stride_maps(MapsArgs a) {
+__device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
   int local;
-  const int f = level_of_chunk(a, 0, local);
+  const int f = level_of_chunk(a, 0, local, bid);
   if (f >= NLV - 1) return;
   const int c = f + 1;
   const int nchunks = a.chunk_off[f + 1] - a.chunk_off[f];
@@ -154,6 +153,20 @@ __global__ __launch_bounds__(256) void k_build_stride_maps(MapsArgs a) {
       tile_mask_or(a.tmdown[c], u, k, row >= 0);
     }
   }
+}
+
+// Kernel maps of all levels in ONE launch: workgroups
+//   [0, n_nbr)   3x3x3x3 neighbour tables: chunk = bid % nchunk, (dy,dz,dt) combo = bid / nchunk
+//   the rest     stride maps (down / up) of the four level pairs
+// (conv0, which also only needs the block structure, stays a launch of its own: merged in here it costs the map
+//  part two waves of occupancy and, dispatched after 28 k map workgroups, overlaps with nothing: 63 us merged
+//  vs 59 us apart)
+__global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int nchunk, int n_nbr) {
+  const int bid = (int)blockIdx.x;
+  if (bid < n_nbr)
+    build_nbr3(ma, bid % nchunk, bid / nchunk);
+  else
+    build_stride_maps(ma, bid - n_nbr);
 }
 
 __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, const int *__restrict__ n_ptr,

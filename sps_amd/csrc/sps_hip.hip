@@ -800,6 +800,9 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   // DIAGNOSTICS ONLY (tools/stage_cost.sh): SPS_DIAG_SKIP bit 0 = reuse the coordinate structures of the
   // previous forward (valid for an identical input), bit 1 = skip the convolutions.  Never set in product use.
   static const int diag_skip = [] { const char *e = getenv("SPS_DIAG_SKIP"); return e ? atoi(e) : 0; }();
+  // DIAGNOSTICS: SPS_NO_MERGE bit i launches the parts of merged kernel i separately (0 rows|ancestors,
+  // 1 link|adj, 2 nbr3|stride maps, 3 slice|cleanup)
+  static const int no_merge = [] { const char *e = getenv("SPS_NO_MERGE"); return e ? atoi(e) : 0; }();
   const bool skip_front = (diag_skip & 1) && c->last_n == n && c->diag_have_state;
   const bool skip_convs = (diag_skip & 2) != 0;
   c->last_n = n;
@@ -816,9 +819,10 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     HIP_TRY(hipMemsetAsync(c->hash_first_all, 0x7F, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(int), st));
     HIP_TRY(hipMemsetAsync(c->hash_occ_all, 0, (size_t)(c->hcap / 32) * SPS_NUM_LEVELS * sizeof(uint32_t), st));
   }
+  if (c->tables_dirty) HIP_TRY(hipMemsetAsync(c->zero_region, 0, c->zero_bytes, st));
   c->tables_dirty = true;
-  HIP_TRY(hipMemsetAsync(c->zero_region, 0, c->zero_bytes, st));  // counts + every tile mask, one fill
   if (n == 0) {
+    HIP_TRY(hipMemsetAsync(c->zero_region, 0, c->zero_bytes, st));  // counts + every tile mask
     c->tables_dirty = false;
     return SPS_OK;
   }
@@ -828,12 +832,22 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   const unsigned gp = (unsigned)((n + 255) / 256);
   const unsigned gs0 = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   const unsigned gsb = (unsigned)(cap / SCAN_BLOCK);  // bound for scans over blocks
+  // (the first kernel also clears the counters and tile masks of the previous forward)
   hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, fo.t_base, L0.h, L0.sslot, L0.sbit,
-                     c->err);
+                     c->err, reinterpret_cast<uint4 *>(c->zero_region), (int)(c->zero_bytes / 16));
   hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
-  hipLaunchKernelGGL(k_points_rows, dim3(gp), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
-                     L0.vblock, L0.vbit);
+  // ---- point rows + (levels 1..4) every coarser level straight from the level-0 blocks, one launch
+  const int gb = grid_for(cap >> 2, 256, 256);
+  if (no_merge & 1) {
+    hipLaunchKernelGGL(k_rows_ancestors, dim3(gp), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
+                       L0.vblock, L0.vbit, pa, (int)gp, gb);
+    hipLaunchKernelGGL(k_rows_ancestors, dim3(4 * gb), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
+                       L0.vblock, L0.vbit, pa, 0, gb);
+  } else {
+    hipLaunchKernelGGL(k_rows_ancestors, dim3(gp + 4 * gb), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase,
+                       L0.inv, L0.vblock, L0.vbit, pa, (int)gp, gb);
+  }
   if (fo.feats) {  // voxel feature = mean of its points' features (App. A.4)
     HIP_TRY(hipMemsetAsync(c->vacc, 0, (size_t)n * sizeof(long long), st));  // V <= n rows are used
     HIP_TRY(hipMemsetAsync(c->vcnt, 0, (size_t)n * sizeof(int), st));
@@ -843,21 +857,22 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   }
   prof_mark(c, "voxelize", st);
   // ---- levels 1..4: every coarser level straight from the level-0 blocks, batched over levels
-  const int gb = grid_for(cap >> 2, 256, 256);
-  const unsigned gsl = gsb > 16 ? gsb / 4 : gsb;  // level-0 blocks are far fewer than points
-  hipLaunchKernelGGL(k_blocks_to_ancestors, dim3(gb, 4), dim3(256), 0, st, pa);
   hipLaunchKernelGGL(k_first_count, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
   hipLaunchKernelGGL(k_first_rank, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
-  hipLaunchKernelGGL(k_link_levels, dim3(gb, 4), dim3(256), 0, st, pa);
-  (void)gsl;
-  prof_mark(c, "pyramid", st);
-  // ---- kernel maps
+  // ---- level links + block adjacency, one launch
   // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
   {
     int co[NLV + 1] = {0};
     for (int l = 0; l < NLV; ++l) co[l + 1] = co[l] + grid_for(((cap >> 3) >> (2 * l)) * 81, 256, 8192);
-    hipLaunchKernelGGL(k_block_adj, dim3(co[NLV]), dim3(256), 0, st, pa, co[1], co[2], co[3], co[4], co[5]);
+    if (no_merge & 2) {
+      hipLaunchKernelGGL(k_link_adj, dim3(4 * gb), dim3(256), 0, st, pa, gb, co[1], co[2], co[3], co[4], co[5]);
+      hipLaunchKernelGGL(k_link_adj, dim3(co[NLV]), dim3(256), 0, st, pa, 0, co[1], co[2], co[3], co[4], co[5]);
+    } else {
+      hipLaunchKernelGGL(k_link_adj, dim3(4 * gb + co[NLV]), dim3(256), 0, st, pa, gb, co[1], co[2], co[3], co[4], co[5]);
+    }
   }
+  prof_mark(c, "pyramid", st);
+  // ---- kernel maps, one launch
   MapsArgs ma{};
   int off = 0;
   for (int l = 0; l < NLV; ++l) {
@@ -876,10 +891,13 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   ma.chunk_off[NLV] = off;
   ma.counts = c->counts;
   ma.ldn = cap;
-  const int gx = grid_for(cap, 256, 1024);
-  (void)gx;  // the 5x5x5x1 map is never materialised: conv0 is fused with it (k_conv0_fused)
-  hipLaunchKernelGGL(k_build_nbr3, dim3(off, 27), dim3(256), 0, st, ma);
-  hipLaunchKernelGGL(k_build_stride_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma);
+  // (the 5x5x5x1 map is never materialised: conv0 is fused with it, k_conv0_fused)
+  if (no_merge & 4) {
+    hipLaunchKernelGGL(k_maps, dim3(off * 27), dim3(256), 0, st, ma, off, off * 27);
+    hipLaunchKernelGGL(k_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, 0);
+  } else {
+    hipLaunchKernelGGL(k_maps, dim3(off * 27 + ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, off * 27);
+  }
   c->diag_have_state = true;
   }  // !skip_front
   prof_mark(c, "maps", st);
@@ -921,18 +939,23 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     prof_mark(c, cc.name, st);
   }
   c->cur_vfeat = nullptr;
+  const int gs = (int)((n + 255) / 256), gbc = grid_for(cap >> 2, 256, 256);
   if (fo.head) {
     const NetSpec &s = *c->net;
     const ConvSpec &fs = s.convs[s.find_conv("final")];
-    hipLaunchKernelGGL(k_slice_head, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->b8o, 8, L0.inv, (int)n,
+    hipLaunchKernelGGL(k_slice_head, dim3((unsigned)gs), dim3(256), 0, st, c->b8o, 8, L0.inv, (int)n,
                        c->blob + fs.w_off, c->blob + s.bias_off, s.out_channels, fo.act, scores, fo.ldo);
+    prof_mark(c, "slice_head", st);
+    if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
+  } else if (skip_front || (no_merge & 8)) {
+    hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)gs), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores);
+    if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
   } else {
-    hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->logits, L0.inv, (int)n,
-                       scores);
+    // slice + sigmoid and the hash clean-up, one launch
+    hipLaunchKernelGGL(k_tail, dim3((unsigned)(gs + gbc * NLV)), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores, gs,
+                       pa, gbc);
   }
-  prof_mark(c, "slice_sigmoid", st);
-  if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(grid_for(cap >> 2, 256, 256), NLV), dim3(256), 0, st, pa);
-  prof_mark(c, "cleanup", st);
+  prof_mark(c, "tail", st);
   HIP_TRY(hipGetLastError());
   c->tables_dirty = false;
   return SPS_OK;
