@@ -83,15 +83,63 @@ __device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int
 // nbr[k*ldn + u] = row of the voxel at (coordinate of u) + offset_k, or -1   (App. A.6-A.8)
 //   3x3x3x3 (all levels): k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1); blockIdx.y = (dy,dz,dt) combo
 // offsets are in units of the level's stride (the block grid already is).
-__device__ inline void build_nbr3(const MapsArgs &a, int bid, int c) {
+// One thread per row walks all 27 (dy,dz,dt) runs of three dx neighbours.  The 81-bit present-offset mask of
+// a 16-row tile is assembled in registers from ballots (every lane of the tile's 16-lane group holds the same
+// words) and written with ONE plain 16-byte store: no atomics, and the mask words need no zero fill.
+__device__ inline void build_nbr3(const MapsArgs &a, int bid) {
   int local;
   const int l = level_of_chunk(a, 0, local, bid);
   const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
   const int n = a.counts[l];
-  const int dy = c % 3 - 1, dz = (c / 3) % 3 - 1, dt = c / 9 - 1;
   const LevelView L = a.L[l];
-  for (int u = local * 256 + threadIdx.x; u < n; u += nchunks * 256)
-    lookup_run<1>(L, u, dy, dz, dt, 3 * c, a.nbr3[l], a.ldn, a.tm3[l]);
+  int *__restrict__ nbr = a.nbr3[l];
+  uint32_t *__restrict__ tmask = a.tm3[l];
+  const int64_t ldn = a.ldn;
+  const int lane = threadIdx.x & 63;
+  const int nround = (n + 63) & ~63;  // whole waves take part in the ballots
+  for (int u = local * 256 + (int)threadIdx.x; u < nround; u += nchunks * 256) {
+    const bool ok = u < n;
+    const int r = ok ? L.vblock[u] : 0;
+    const int bit = ok ? L.vbit[u] : 0;
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const int *__restrict__ adj = L.badj + (size_t)r * 81;
+    uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
+#pragma unroll 3
+    for (int c = 0; c < 27; ++c) {
+      const int dy = c % 3 - 1, dz = (c / 3) % 3 - 1, dt = c / 9 - 1;
+      const int ty = py + dy, tz = pz + dz;
+      const int ad0 = (dt + 1) * 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
+      const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
+      // the run x = px-1 .. px+1 touches the block at offset 0 and at most one of the blocks at -1 / +1
+      const int side = px == 0 ? -1 : (px == 3 ? 1 : 0);
+      const int nb_c = ok ? adj[ad0] : -1;
+      const int nb_s = (ok && side != 0) ? adj[ad0 + side] : -1;
+      const unsigned long long mk_c = nb_c >= 0 ? L.bmask[nb_c] : 0ull;
+      const int base_c = nb_c >= 0 ? L.bbase[nb_c] : 0;
+      const unsigned long long mk_s = nb_s >= 0 ? L.bmask[nb_s] : 0ull;
+      const int base_s = nb_s >= 0 ? L.bbase[nb_s] : 0;
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int tx = px + dx;
+        const bool centre = (tx >> 2) == 0;
+        const unsigned long long mk = centre ? mk_c : mk_s;
+        const int base = centre ? base_c : base_s;
+        const int nbit = nbit0 | (tx & 3);
+        int row = -1;
+        if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
+        const int k = 3 * c + dx + 1;
+        const unsigned long long bal = __ballot(row >= 0);
+        const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
+        // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
+        if (any && ok) nbr[(size_t)k * ldn + u] = row;
+        const uint32_t b = any ? 1u << (k & 31) : 0u;
+        m0 |= (k >> 5) == 0 ? b : 0u;
+        m1 |= (k >> 5) == 1 ? b : 0u;
+        m2 |= (k >> 5) == 2 ? b : 0u;
+      }
+    }
+    if ((lane & 15) == 0 && ok) *reinterpret_cast<uint4 *>(tmask + (size_t)(u >> 4) * 4) = make_uint4(m0, m1, m2, 0u);
+  }
 }
 
 //   5x5x5x1 (level 0): k = (dx+2) + 5(dy+2) + 25(dz+2); blockIdx.y = (dy,dz) combo
@@ -155,16 +203,14 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
   }
 }
 
-// Kernel maps of all levels in ONE launch: workgroups
-//   [0, n_nbr)   3x3x3x3 neighbour tables: chunk = bid % nchunk, (dy,dz,dt) combo = bid / nchunk
-//   the rest     stride maps (down / up) of the four level pairs
+// Kernel maps of all levels in ONE launch: workgroups [0, n_nbr) build the 3x3x3x3 neighbour tables (256 rows
+// each, all 81 offsets), the rest the stride maps (down / up) of the four level pairs.
 // (conv0, which also only needs the block structure, stays a launch of its own: merged in here it costs the map
-//  part two waves of occupancy and, dispatched after 28 k map workgroups, overlaps with nothing: 63 us merged
-//  vs 59 us apart)
-__global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int nchunk, int n_nbr) {
+//  part two waves of occupancy and overlaps with nothing: 63 us merged vs 59 us apart)
+__global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int n_nbr) {
   const int bid = (int)blockIdx.x;
   if (bid < n_nbr)
-    build_nbr3(ma, bid % nchunk, bid / nchunk);
+    build_nbr3(ma, bid);
   else
     build_stride_maps(ma, bid - n_nbr);
 }

@@ -159,7 +159,7 @@ struct sps_ctx {
   SubmapScratch sub;
   bool tables_dirty = true;  // block hashes need a full reset (first use / aborted forward)
   void *hash_keys_all = nullptr, *hash_mask_all = nullptr, *hash_first_all = nullptr, *hash_occ_all = nullptr;
-  int *nbr5 = nullptr;       // [125][cap]
+  int *nbr5 = nullptr;       // [125][cap], introspection only: allocated by the first sps_get_map_pairs(ctx, 5)
   int *counts = nullptr;     // device: [0..4] voxels per level, [5] submap rows, [6] scan voxels, [8..12] blocks per level
   int *err = nullptr;        // device error flag
   int *block_sums = nullptr;
@@ -215,6 +215,7 @@ void free_arena(sps_ctx *c) {
   for (void *p : c->allocs) (void)hipFree(p);
   c->allocs.clear();
   c->cap = 0;
+  c->nbr5 = nullptr;
 }
 
 #define ALLOC(ptr, type, count)                                             \
@@ -281,26 +282,27 @@ int reserve(sps_ctx *c, int64_t n) {
     ALLOC(c->sub.srckey, uint64_t, cap);
     ALLOC(c->sub.pslot, int, cap);
   }
-  ALLOC(c->nbr5, int, 125 * cap);
   {
     const size_t tm_words = (size_t)(cap / 16) * 4;  // cap is a multiple of 1024
     uint32_t *zr;
     ALLOC(zr, uint32_t, 16 + tm_words * 14);
     c->zero_region = zr;
-    c->zero_bytes = (16 + tm_words * 14) * sizeof(uint32_t);
+    // zeroed at the start of every forward: counters, the 5x5x5 debug masks and the stride-map masks (built with
+    // atomicOr); the 3x3x3x3 masks behind them are overwritten tile by tile and need no fill
+    c->zero_bytes = (16 + tm_words * 9) * sizeof(uint32_t);
     c->counts = reinterpret_cast<int *>(zr);
     uint32_t *p = zr + 16;
     c->tm5 = p;
     p += tm_words;
+    for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
+      c->lv[l].tmdown = p;
+      p += tm_words;
+      c->lv[l].tmup = p;
+      p += tm_words;
+    }
     for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
       c->lv[l].tm3 = p;
       p += tm_words;
-      if (l > 0) {
-        c->lv[l].tmdown = p;
-        p += tm_words;
-        c->lv[l].tmup = p;
-        p += tm_words;
-      }
     }
   }
   ALLOC(c->block_sums, int, 2 * (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
@@ -893,10 +895,10 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   ma.ldn = cap;
   // (the 5x5x5x1 map is never materialised: conv0 is fused with it, k_conv0_fused)
   if (no_merge & 4) {
-    hipLaunchKernelGGL(k_maps, dim3(off * 27), dim3(256), 0, st, ma, off, off * 27);
-    hipLaunchKernelGGL(k_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, 0);
+    hipLaunchKernelGGL(k_maps, dim3(off), dim3(256), 0, st, ma, off);
+    hipLaunchKernelGGL(k_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, 0);
   } else {
-    hipLaunchKernelGGL(k_maps, dim3(off * 27 + ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, off * 27);
+    hipLaunchKernelGGL(k_maps, dim3(off + ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off);
   }
   c->diag_have_state = true;
   }  // !skip_front
@@ -1241,6 +1243,7 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
   HIP_TRY(hipSetDevice(c->device));
   const int K = which == 5 ? 125 : 81;
   const int level = which == 5 ? 0 : which;
+  if (which == 5 && !c->nbr5 && c->cap > 0) ALLOC(c->nbr5, int, 125 * c->cap);
   const int *nbr = which == 5 ? c->nbr5 : c->lv[which].nbr3;
   if (which == 5)  // debug only: materialise the 5x5x5x1 table from the (still valid) block tables
     hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0,
