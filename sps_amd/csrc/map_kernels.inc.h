@@ -165,41 +165,59 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
   const int nchunks = a.chunk_off[f + 1] - a.chunk_off[f];
   const LevelView F = a.L[f], C = a.L[c];
   const int nf = a.counts[f], nc = a.counts[c];
-  // ---- up map + parent rows (rows = fine voxels)
-  for (int v = local * 256 + threadIdx.x; v < nf; v += nchunks * 256) {
-    const int r = F.vblock[v];
-    const int bit = F.vbit[v];
-    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
-    const uint64_t key = F.bkey[r];
-    const int ox = (int)(key & 1), oy = (int)((key >> 18) & 1), oz = (int)((key >> 36) & 1);
-    const int pr = F.bparent[r];
-    const int pbit = ((oz * 2 + (pz >> 1)) << 4) | ((oy * 2 + (py >> 1)) << 2) | (ox * 2 + (px >> 1));
-    const int par = C.bbase[pr] + __popcll(C.bmask[pr] & ((1ull << pbit) - 1ull));
-    const int oct = (px & 1) | ((py & 1) << 1) | ((pz & 1) << 2);
-    a.parent_row[c][v] = par;
+  const int lane = threadIdx.x & 63;
+  // ---- up map + parent rows (rows = fine voxels); tile masks from ballots, one plain store per tile
+  const int nfr = (nf + 63) & ~63;
+  for (int v = local * 256 + (int)threadIdx.x; v < nfr; v += nchunks * 256) {
+    const bool ok = v < nf;
+    int par = -1, oct = 8;
+    if (ok) {
+      const int r = F.vblock[v];
+      const int bit = F.vbit[v];
+      const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+      const uint64_t key = F.bkey[r];
+      const int ox = (int)(key & 1), oy = (int)((key >> 18) & 1), oz = (int)((key >> 36) & 1);
+      const int pr = F.bparent[r];
+      const int pbit = ((oz * 2 + (pz >> 1)) << 4) | ((oy * 2 + (py >> 1)) << 2) | (ox * 2 + (px >> 1));
+      par = C.bbase[pr] + __popcll(C.bmask[pr] & ((1ull << pbit) - 1ull));
+      oct = (px & 1) | ((py & 1) << 1) | ((pz & 1) << 2);
+      a.parent_row[c][v] = par;
+    }
+    uint32_t m = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      a.up[c][(size_t)k * a.ldn + v] = (k == oct) ? par : -1;
-      tile_mask_or(a.tmup[c], v, k, k == oct);
+      if (ok) a.up[c][(size_t)k * a.ldn + v] = (k == oct) ? par : -1;
+      const unsigned long long bal = __ballot(k == oct);
+      m |= ((bal >> (lane & 48)) & 0xFFFFull) != 0ull ? 1u << k : 0u;
     }
+    if ((lane & 15) == 0 && ok) *reinterpret_cast<uint4 *>(a.tmup[c] + (size_t)(v >> 4) * 4) = make_uint4(m, 0u, 0u, 0u);
   }
   // ---- down map (rows = coarse voxels)
-  for (int u = local * 256 + threadIdx.x; u < nc; u += nchunks * 256) {
-    const int r = C.vblock[u];
-    const int bit = C.vbit[u];
-    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
-    const int cb = C.bchild[(size_t)r * 8 + ((px >> 1) | ((py >> 1) << 1) | ((pz >> 1) << 2))];
-    const unsigned long long mk = cb >= 0 ? F.bmask[cb] : 0ull;
-    const int base = cb >= 0 ? F.bbase[cb] : 0;
+  const int ncr = (nc + 63) & ~63;
+  for (int u = local * 256 + (int)threadIdx.x; u < ncr; u += nchunks * 256) {
+    const bool ok = u < nc;
+    int px = 0, py = 0, pz = 0, base = 0;
+    unsigned long long mk = 0ull;
+    if (ok) {
+      const int r = C.vblock[u];
+      const int bit = C.vbit[u];
+      px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+      const int cb = C.bchild[(size_t)r * 8 + ((px >> 1) | ((py >> 1) << 1) | ((pz >> 1) << 2))];
+      mk = cb >= 0 ? F.bmask[cb] : 0ull;
+      base = cb >= 0 ? F.bbase[cb] : 0;
+    }
+    uint32_t m = 0u;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int dx = k & 1, dy = (k >> 1) & 1, dz = (k >> 2) & 1;
       const int cbit = ((((pz & 1) << 1) + dz) << 4) | ((((py & 1) << 1) + dy) << 2) | (((px & 1) << 1) + dx);
       int row = -1;
       if ((mk >> cbit) & 1ull) row = base + __popcll(mk & ((1ull << cbit) - 1ull));
-      a.down[c][(size_t)k * a.ldn + u] = row;
-      tile_mask_or(a.tmdown[c], u, k, row >= 0);
+      if (ok) a.down[c][(size_t)k * a.ldn + u] = row;
+      const unsigned long long bal = __ballot(row >= 0);
+      m |= ((bal >> (lane & 48)) & 0xFFFFull) != 0ull ? 1u << k : 0u;
     }
+    if ((lane & 15) == 0 && ok) *reinterpret_cast<uint4 *>(a.tmdown[c] + (size_t)(u >> 4) * 4) = make_uint4(m, 0u, 0u, 0u);
   }
 }
 

@@ -287,9 +287,9 @@ int reserve(sps_ctx *c, int64_t n) {
     uint32_t *zr;
     ALLOC(zr, uint32_t, 16 + tm_words * 14);
     c->zero_region = zr;
-    // zeroed at the start of every forward: counters, the 5x5x5 debug masks and the stride-map masks (built with
-    // atomicOr); the 3x3x3x3 masks behind them are overwritten tile by tile and need no fill
-    c->zero_bytes = (16 + tm_words * 9) * sizeof(uint32_t);
+    // zeroed at the start of every forward: the counters only.  Every tile-mask array behind them is overwritten
+    // tile by tile by the forward that uses it (the 5x5x5 debug masks are cleared by their getter)
+    c->zero_bytes = 16 * sizeof(uint32_t);
     c->counts = reinterpret_cast<int *>(zr);
     uint32_t *p = zr + 16;
     c->tm5 = p;
@@ -1245,6 +1245,7 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
   const int level = which == 5 ? 0 : which;
   if (which == 5 && !c->nbr5 && c->cap > 0) ALLOC(c->nbr5, int, 125 * c->cap);
   const int *nbr = which == 5 ? c->nbr5 : c->lv[which].nbr3;
+  if (which == 5) HIP_TRY(hipMemset(c->tm5, 0, (size_t)(c->cap / 16) * 4 * sizeof(uint32_t)));
   if (which == 5)  // debug only: materialise the 5x5x5x1 table from the (still valid) block tables
     hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0,
                        c->lv[0].view(), c->nbr5, c->cap, c->tm5);
