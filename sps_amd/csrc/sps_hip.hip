@@ -450,6 +450,10 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   int64_t gx = (c->cap / 64) >> cc.level_out;
   if (gx < 64) gx = 64;
   if (gx > 4096) gx = 4096;
+  {
+    static const float gscale = [] { const char *e = getenv("SPS_GRID_SCALE"); return e ? (float)atof(e) : 1.f; }();  // DIAGNOSTICS
+    if (gscale != 1.f) gx = std::max<int64_t>(16, (int64_t)((float)gx * gscale));
+  }
   static const int max_wg = [] { const char *e = getenv("SPS_CONV_MAX_WG"); return e ? atoi(e) : 0; }();
   if (max_wg > 0 && gx * (a.NT / g.ntw) * g.S > max_wg) gx = std::max<int64_t>(16, max_wg / ((a.NT / g.ntw) * g.S));
   // a workgroup holds 4 / S tiles x S splits: S times as many workgroups for the same tiles
