@@ -58,7 +58,10 @@ struct ConvArgs {
 //   with a 32-bit voffset, so the address arithmetic is one add per load, and an absent neighbour is
 //   the out-of-range offset OOR, for which the hardware returns zeros (no branch, no select); (k, c4)
 //   advance incrementally instead of by division.
-constexpr int KCHUNK = 32;
+#ifndef SPS_KCHUNK
+#define SPS_KCHUNK 32
+#endif
+constexpr int KCHUNK = SPS_KCHUNK;
 constexpr uint32_t OOR = 0xFFFF0000u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
