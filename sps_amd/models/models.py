@@ -56,6 +56,7 @@ class NativeBackboneModule(nn.Module):
     def _init_backbone(self, out_channels: int) -> None:
         self.MinkUNet = CustomMinkUNet(in_channels=1, out_channels=out_channels, D=4)
         self._loaded_ctxs = set()        # native contexts that currently hold this module's weights
+        self._blob = None                # host copy of the weight blob in the native layout
         # any load_state_dict that reaches the backbone (predict.py:58 or util.py:39) re-uploads
         self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self.mark_weights_dirty())
 
@@ -63,9 +64,11 @@ class NativeBackboneModule(nn.Module):
     def mark_weights_dirty(self) -> None:
         """Call after modifying parameters in place; load_state_dict / .cuda() / .to() do it themselves."""
         self._loaded_ctxs = set()
+        self._blob = None
 
     def _apply(self, fn, *args, **kwargs):
         self._loaded_ctxs = set()
+        self._blob = None
         return super()._apply(fn, *args, **kwargs)
 
     def _sync_weights(self, ctx) -> None:
@@ -73,13 +76,16 @@ class NativeBackboneModule(nn.Module):
         if id(ctx) in self._loaded_ctxs and owner is not None and owner() is self:
             return                       # this module's weights are the ones resident in ctx
         oc = self.MinkUNet.out_channels
-        sd = self.MinkUNet.state_dict()
-        blob = np.empty(_native.lib.sps_head_numel(oc), dtype=np.float32)
-        for name, off, numel in _native.weight_layout(oc):
-            t = sd[name].detach().to("cpu", torch.float32).contiguous().reshape(-1)
-            if t.numel() != numel:
-                raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
-            blob[off: off + numel] = t.numpy()
+        blob = self._blob
+        if blob is None:                 # packed once per parameter version, shared by every (device, stream) context
+            sd = self.MinkUNet.state_dict()
+            blob = np.empty(_native.lib.sps_head_numel(oc), dtype=np.float32)
+            for name, off, numel in _native.weight_layout(oc):
+                t = sd[name].detach().to("cpu", torch.float32).contiguous().reshape(-1)
+                if t.numel() != numel:
+                    raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
+                blob[off: off + numel] = t.numpy()
+            self._blob = blob
         ctx.load_weights(blob.ctypes.data, blob.size, oc)
         ctx.weights_owner = weakref.ref(self)   # a context is shared by every model on its device/stream
         self._loaded_ctxs.add(id(ctx))
