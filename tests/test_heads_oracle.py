@@ -62,3 +62,22 @@ def test_head_columns_are_independent_linear_maps():
         p1["final.bias"] = p3["final.bias"][:, j:j + 1].copy()
         one, _ = o.head_forward(p1, c, 0.2)
         np.testing.assert_allclose(one[:, 0], full[:, j], rtol=0, atol=1e-6)
+
+
+def test_head_blob_layout_matches_parameter_containers():
+    """The native k-channel layouts (sps_head_tensor_info) name exactly the tensors of the Python containers, with
+    the reference's state_dict keys and sizes (final.kernel [8,k], final.bias [1,k]); no GPU needed."""
+    from sps_amd import _native
+    from sps_amd.models.baselines import MapMOSNet, MOS4DNet
+    for model, oc in ((MOS4DNet(0.2), 3), (MapMOSNet(0.1), 1)):
+        sd = {k: v for k, v in model.MinkUNet.state_dict().items() if not k.endswith("num_batches_tracked")}
+        layout = _native.weight_layout(oc)
+        assert {n for n, _, _ in layout} == set(sd)
+        off = 0
+        for name, o, numel in layout:
+            assert o == off and sd[name].numel() == numel, name
+            off += numel
+        assert off == _native.lib.sps_head_numel(oc)
+        assert tuple(sd["final.kernel"].shape) == (8, oc) and tuple(sd["final.bias"].shape) == (1, oc)
+    assert _native.lib.sps_head_numel(1) == _native.lib.sps_weights_numel()
+    assert _native.lib.sps_head_numel(9) < 0            # out of range is an error, not a crash
