@@ -381,6 +381,86 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 #endif
 }
 
+// Transposed (up-sampling) convolution, parent-stationary (App. A.10: every fine voxel v receives exactly one
+// term, in[parent(v)] @ W[oct(v)]).  Run output-stationary through k_conv it executes all 8 offsets for every
+// fine tile although one row in eight is live per offset; here a workgroup owns a tile of 16 PARENT rows:
+// its features are loaded once (contiguous rows, all units kept in registers), wave w multiplies them with
+// the weights of offsets 2w and 2w+1 and scatters the 16 x C_out results to the children given by the stride
+// map's `down` table (each child is written exactly once -> no atomics; the per-element MFMA sequence is the
+// one k_conv would run, so the results are bit-identical).  a.n_out / a.nbr / a.tmask are the COARSE level's
+// row count, down table and down masks; a.out is the fine level's concat buffer.
+template <int NT>
+__global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
+  const int count = *a.n_out;
+  const int ntiles = (count + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
+  const int upk = a.upk;            // 4, 8 or 16 units (C_in = 16, 32, 64)
+  const int ngrp = upk >> 2;        // unit groups of 4 (one per lane group q)
+  float esc[NT], esh[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int col = nt * 16 + r;
+    esc[nt] = col < a.cout ? a.scale[col] : 0.f;
+    esh[nt] = col < a.cout ? a.shift[col] : 0.f;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * 16;
+    const uint32_t mask = a.tmask[(size_t)tile * 4] & 0xFFu;
+    const int row = row0 + r;
+    u32x4 va[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t oa = (i < ngrp && row < count) ? (uint32_t)row * ((uint32_t)a.ldi * 4u) + (uint32_t)(4 * i + q) * 16u : OOR;
+      va[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = 2 * wave + kk;
+      if (!((mask >> k) & 1u)) continue;  // no row of this tile has a child at octant k (wave-uniform)
+      int child[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int ro = row0 + q * 4 + i;
+        child[i] = ro < count ? a.nbr[(size_t)k * a.ldn + ro] : -1;
+      }
+      floatx4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (i >= ngrp) break;
+        const uint32_t ob = ((uint32_t)(k * upk + 4 * i + q) * (uint32_t)NT) * 256u + (uint32_t)r * 16u;
+        u32x4 vb[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) vb[nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].x), __uint_as_float(vb[nt].x), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].y), __uint_as_float(vb[nt].y), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].z), __uint_as_float(vb[nt].z), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].w), __uint_as_float(vb[nt].w), acc[nt], 0, 0, 0);
+        }
+      }
+      // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int col = nt * 16 + r;
+        if (col >= a.cout) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (child[i] < 0) continue;
+          float y = acc[nt][i] * esc[nt] + esh[nt];
+          if (a.relu) y = fmaxf(y, 0.f);
+          a.out[(size_t)child[i] * a.ldo + col] = y;
+        }
+      }
+    }
+  }
+}
+
 // conv0p1s1 (5x5x5x1, 1 -> 8, minkunet.py:55-62) fused with its kernel map.  The input feature is
 // the constant 0.5 (models.py:22; mean of 0.5s, App. A.4), so only the PRESENCE of each of the 125
 // neighbours matters: out[u] = sum_{k present} 0.5 * W[k], k ascending (App. A.8), then BN + ReLU.

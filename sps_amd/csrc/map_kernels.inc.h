@@ -34,8 +34,8 @@ struct MapsArgs {
   LevelView L[NLV];
   int *nbr3[NLV];
   uint32_t *tm3[NLV];
-  int *down[NLV], *up[NLV], *parent_row[NLV];  // index = coarse level (1..4)
-  uint32_t *tmdown[NLV], *tmup[NLV];
+  int *down[NLV], *parent_row[NLV];  // index = coarse level (1..4)
+  uint32_t *tmdown[NLV];
   const int *counts;
   int chunk_off[NLV + 1];
   int64_t ldn;
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void k_build_nbr5(const int *__restrict__ n_ou
 // Stride maps of all four level pairs in one launch.  chunk_off here is indexed by the FINE level
 // f = 0..3 (coarse level c = f + 1); each workgroup does both directions for its rows:
 //  down (App. A.9):  out = coarse voxel u, children at u + {0,1}^3 (fine units), k = dx + 2dy + 4dz
-//  up   (App. A.10): fine voxel v receives exactly one term, from its parent, through offset
-//                    k = position of v inside the parent: up[k*ldn + v] = (k == oct(v)) ? parent : -1
+//  up   (App. A.10): fine voxel v receives exactly one term, from its parent, through offset k = position of v
+//                    inside the parent: the transposed convs read the SAME down table with the roles swapped
 __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
   int local;
   const int f = level_of_chunk(a, 0, local, bid);
@@ -166,31 +166,17 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
   const LevelView F = a.L[f], C = a.L[c];
   const int nf = a.counts[f], nc = a.counts[c];
   const int lane = threadIdx.x & 63;
-  // ---- up map + parent rows (rows = fine voxels); tile masks from ballots, one plain store per tile
-  const int nfr = (nf + 63) & ~63;
-  for (int v = local * 256 + (int)threadIdx.x; v < nfr; v += nchunks * 256) {
-    const bool ok = v < nf;
-    int par = -1, oct = 8;
-    if (ok) {
-      const int r = F.vblock[v];
-      const int bit = F.vbit[v];
-      const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
-      const uint64_t key = F.bkey[r];
-      const int ox = (int)(key & 1), oy = (int)((key >> 18) & 1), oz = (int)((key >> 36) & 1);
-      const int pr = F.bparent[r];
-      const int pbit = ((oz * 2 + (pz >> 1)) << 4) | ((oy * 2 + (py >> 1)) << 2) | (ox * 2 + (px >> 1));
-      par = C.bbase[pr] + __popcll(C.bmask[pr] & ((1ull << pbit) - 1ull));
-      oct = (px & 1) | ((py & 1) << 1) | ((pz & 1) << 2);
-      a.parent_row[c][v] = par;
-    }
-    uint32_t m = 0u;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      if (ok) a.up[c][(size_t)k * a.ldn + v] = (k == oct) ? par : -1;
-      const unsigned long long bal = __ballot(k == oct);
-      m |= ((bal >> (lane & 48)) & 0xFFFFull) != 0ull ? 1u << k : 0u;
-    }
-    if ((lane & 15) == 0 && ok) *reinterpret_cast<uint4 *>(a.tmup[c] + (size_t)(v >> 4) * 4) = make_uint4(m, 0u, 0u, 0u);
+  // ---- parent rows (rows = fine voxels).  The transposed convs run parent-stationary over the DOWN table
+  // (k_upconv), so no separate up table is built.
+  for (int v = local * 256 + (int)threadIdx.x; v < nf; v += nchunks * 256) {
+    const int r = F.vblock[v];
+    const int bit = F.vbit[v];
+    const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    const uint64_t key = F.bkey[r];
+    const int ox = (int)(key & 1), oy = (int)((key >> 18) & 1), oz = (int)((key >> 36) & 1);
+    const int pr = F.bparent[r];
+    const int pbit = ((oz * 2 + (pz >> 1)) << 4) | ((oy * 2 + (py >> 1)) << 2) | (ox * 2 + (px >> 1));
+    a.parent_row[c][v] = C.bbase[pr] + __popcll(C.bmask[pr] & ((1ull << pbit) - 1ull));
   }
   // ---- down map (rows = coarse voxels)
   const int ncr = (nc + 63) & ~63;

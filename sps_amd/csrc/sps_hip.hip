@@ -129,8 +129,7 @@ struct Level {
   // kernel maps
   int *nbr3 = nullptr;         // [81][cap]
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
-  int *up = nullptr;           // [8][cap]  (levels 1..4) indexed by level-1 voxel
-  uint32_t *tm3 = nullptr, *tmdown = nullptr, *tmup = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
+  uint32_t *tm3 = nullptr, *tmdown = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
   LevelView view() const { return LevelView{vblock, vbit, bkey, bmask, bbase, badj, bparent, bchild}; }
 };
 
@@ -271,7 +270,6 @@ int reserve(sps_ctx *c, int64_t n) {
       ALLOC(L.nbr3, int, 81 * cap);
       if (l > 0) {
         ALLOC(L.down, int, 8 * cap);
-        ALLOC(L.up, int, 8 * cap);
       }
     }
     c->tables_dirty = true;
@@ -296,8 +294,6 @@ int reserve(sps_ctx *c, int64_t n) {
     p += tm_words;
     for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
       c->lv[l].tmdown = p;
-      p += tm_words;
-      c->lv[l].tmup = p;
       p += tm_words;
     }
     for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
@@ -486,6 +482,26 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
                        c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
     return SPS_OK;
+  }
+  if (cs.K == 8 && std::strncmp(cc.name, "convtr", 6) == 0) {
+    // transposed conv: parent-stationary kernel over the COARSE level's rows (k_upconv)
+    {
+      const int coarse = cc.level_out + 1;
+      a.nbr = c->lv[coarse].down;
+      a.tmask = c->lv[coarse].tmdown;
+      a.n_out = c->counts + coarse;
+      int64_t gu = (c->cap / 16) >> coarse;  // one workgroup per 16 parent rows
+      if (gu < 64) gu = 64;
+      if (gu > 8192) gu = 8192;
+      const dim3 gr((unsigned)gu);
+      if (a.NT == 1)
+        hipLaunchKernelGGL((k_upconv<1>), gr, dim3(256), 0, st, a);
+      else if (a.NT == 2)
+        hipLaunchKernelGGL((k_upconv<2>), gr, dim3(256), 0, st, a);
+      else
+        hipLaunchKernelGGL((k_upconv<4>), gr, dim3(256), 0, st, a);
+      return SPS_OK;
+    }
   }
   const bool ds = cs.ds_cin > 0;
   // EXPERIMENT, off by default: on MI355X the row-compacting kernel is slower than k_conv (block8.conv1
@@ -887,10 +903,8 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     ma.nbr3[l] = L.nbr3;
     ma.tm3[l] = L.tm3;
     ma.down[l] = L.down;
-    ma.up[l] = L.up;
     ma.parent_row[l] = L.inv;
     ma.tmdown[l] = L.tmdown;
-    ma.tmup[l] = L.tmup;
     ma.chunk_off[l] = off;
     off += grid_for(cap >> l, 256, 1024);
   }
@@ -925,16 +939,16 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
       {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, Map{lv[4].down, lv[4].tmdown}, 4, nullptr, 0, 1},
       {"block4.0.conv1", c->x4, 32, c->b4t, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1},
       {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1, c->x4, 32},
-      {"convtr4p16s2", c->b4o, 64, c->cat5, 96, Map{lv[4].up, lv[4].tmup}, 3, nullptr, 0, 1},
+      {"convtr4p16s2", c->b4o, 64, c->cat5, 96, Map{lv[4].down, lv[4].tmdown}, 3, nullptr, 0, 1},
       {"block5.0.conv1", c->cat5, 96, c->b5t, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
       {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->cat5, 96},
-      {"convtr5p8s2", c->b5o, 64, c->cat6, 48, Map{lv[3].up, lv[3].tmup}, 2, nullptr, 0, 1},
+      {"convtr5p8s2", c->b5o, 64, c->cat6, 48, Map{lv[3].down, lv[3].tmdown}, 2, nullptr, 0, 1},
       {"block6.0.conv1", c->cat6, 48, c->b6t, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
       {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1, c->cat6, 48},
-      {"convtr6p4s2", c->b6o, 32, c->cat7, 24, Map{lv[2].up, lv[2].tmup}, 1, nullptr, 0, 1},
+      {"convtr6p4s2", c->b6o, 32, c->cat7, 24, Map{lv[2].down, lv[2].tmdown}, 1, nullptr, 0, 1},
       {"block7.0.conv1", c->cat7, 24, c->b7t, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1},
       {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1, c->cat7, 24},
-      {"convtr7p2s2", c->b7o, 16, c->cat8, 16, Map{lv[1].up, lv[1].tmup}, 0, nullptr, 0, 1},
+      {"convtr7p2s2", c->b7o, 16, c->cat8, 16, Map{lv[1].down, lv[1].tmdown}, 0, nullptr, 0, 1},
       {"block8.0.conv1", c->cat8, 16, c->b8t, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1},
       {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1, c->cat8, 16, fuse_final},
   };
