@@ -88,7 +88,9 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
-  const int nt0 = blockIdx.y * NTW;
+  // grid = (column groups, tile groups): the column groups of one tile are dispatched back to back, so every
+  // workgroup that has work starts before the idle tail of the grid (tile groups past the device-side count)
+  const int nt0 = blockIdx.x * NTW;
   // split-K inside the workgroup: its four waves are (4 / S) tiles x S splits of the tile's unit list; the
   // partial sums meet in LDS (fixed order -> deterministic), so there is no slab in HBM and no second launch
   constexpr int tpw = 4 / S;                           // S = 1, 2 or 4; tiles per workgroup
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const float efw = (FIN && r < a.cout) ? a.fin_w[r] : 0.f;
   // the first tile's mask words do not depend on the row count: fetch them alongside it (saves a
   // dependent round trip; tile_cap = tiles the mask buffer was allocated for)
-  const int tile_first = blockIdx.x * tpw + tl;
+  const int tile_first = blockIdx.y * tpw + tl;
   uint32_t pw0 = 0u, pw1 = 0u;
   if (a.tmask && tile_first < a.tile_cap) {
     pw0 = a.tmask[(size_t)tile_first * 4 + (lane >> 5)];
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   }
   // the loop bound is workgroup-uniform (the S > 1 path has barriers); a wave whose tile lies past the end
   // runs an empty unit list
-  for (int grp = blockIdx.x; grp * tpw < ntiles; grp += gridDim.x) {
+  for (int grp = blockIdx.y; grp * tpw < ntiles; grp += gridDim.y) {
     const int tile = grp * tpw + tl;
     const bool active = tile < ntiles;
     if (S == 1 && !active) continue;
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   }
 #if defined(SPS_WAVE_TRACE)
   if (a.trace_on && lane == 0) {
-    const int w = (blockIdx.x + gridDim.x * blockIdx.y) * 4 + wave;
+    const int w = (blockIdx.x + gridDim.x * blockIdx.y) * 4 + wave;  // dispatch order
     if (w < 32768) {
       g_wave_trace[4 * w + 0] = tr_t0;
       g_wave_trace[4 * w + 1] = tr_t1;

@@ -455,7 +455,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   static const int max_wg = [] { const char *e = getenv("SPS_CONV_MAX_WG"); return e ? atoi(e) : 0; }();
   if (max_wg > 0 && gx * (a.NT / g.ntw) * g.S > max_wg) gx = std::max<int64_t>(16, max_wg / ((a.NT / g.ntw) * g.S));
   // a workgroup holds 4 / S tiles x S splits: S times as many workgroups for the same tiles
-  const dim3 grid((unsigned)(gx * g.S), (unsigned)(a.NT / g.ntw), 1u);
+  const dim3 grid((unsigned)(a.NT / g.ntw), (unsigned)(gx * g.S), 1u);  // x = column group (fastest), y = tile group
   a.in2 = cc.in2;
   a.ldi2 = cc.ldi2;
   a.upk2 = cs.ds_cin / 4;
