@@ -393,6 +393,7 @@ struct Geometry {
   int ntw, S;
 };
 Geometry conv_geometry(int level, int K, int cin, int nt) {
+  if (K == 8 && level >= 3) return {1, 4};  // stride convs into the two coarsest levels: ~100-300 tiles, split four ways
   if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
   const int upk = cin / 4;  // ~30 present offsets x upk units per tile
   Geometry g;
