@@ -221,7 +221,11 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       const int asrc = ((lane >> 2) + 16 * (lane & 3)) * 4;  // lane holding the offset of (row rho, unit qa)
       const int xsrc = (4 * r + q) * 4;  // bpermute byte address of the lane that fetched (row r, unit q)
 #endif
+#if defined(SPS_ABLATE_LOOP)
+      for (int jb = ju0; jb < ju0; jb += 4 * G) {
+#else
       for (int jb = ju0; jb < ju1; jb += 4 * G) {
+#endif
         u32x4 va[G];
         u32x4 vb[G][NTW];
 #pragma unroll
