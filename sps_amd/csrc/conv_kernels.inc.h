@@ -1,5 +1,5 @@
 // conv_kernels.inc.h -- part of the single translation unit sps_hip.hip (included inside its anonymous namespace).
-// sparse convolution kernels (f32 MFMA), conv0 fused with its map, split-K reduction, experimental row compaction.
+// sparse convolution kernels (f32 MFMA), conv0 fused with its map, parent-stationary transposed conv, head kernels.
 
 // ------------------------------------------------------------------------------------------
 // sparse convolution: output-stationary gather + f32 MFMA, fused BN / residual / ReLU epilogue
@@ -64,10 +64,6 @@ struct ConvArgs {
 constexpr int KCHUNK = SPS_KCHUNK;
 constexpr uint32_t OOR = 0xFFFF0000u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-#ifndef SPS_A_QUAD
-#define SPS_A_QUAD 0
-#endif
 
 #if defined(SPS_WAVE_TRACE)
 // DIAGNOSTIC build only (tools/wave_trace.py): per-wave wall-clock stamps (100 MHz) of one chosen layer
@@ -213,14 +209,6 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
       int kk = (int)(((float)jl + 0.5f) * a.inv_upk);
       int c4 = jl - kk * upk;
       kk -= kc;
-#if SPS_A_QUAD
-      // A is FETCHED quad-contiguous: lane L = 4*rho + qa reads unit (4i + qa) of row rho, so the four
-      // lanes of a quad read up to 64 contiguous bytes of ONE row (one TCP request; in the MFMA layout
-      // lane = r + 16 q the quad's pieces lie in four different rows and cost 2-3 TA cycles per quad:
-      // tools/microbench/l1_gather.hip), then 4 ds_bpermute move the pieces to lane r + 16 q.
-      const int asrc = ((lane >> 2) + 16 * (lane & 3)) * 4;  // lane holding the offset of (row rho, unit qa)
-      const int xsrc = (4 * r + q) * 4;  // bpermute byte address of the lane that fetched (row r, unit q)
-#endif
 #if defined(SPS_ABLATE_LOOP)
       for (int jb = ju0; jb < ju0; jb += 4 * G) {
 #else
@@ -235,9 +223,6 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 #if defined(SPS_ABLATE_A)
           const uint32_t oa = OOR;
           (void)ao;
-#elif SPS_A_QUAD
-          const uint32_t oa = (uint32_t)__builtin_amdgcn_ds_bpermute(
-              asrc, (int)(valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR));
 #else
           const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
 #endif
@@ -255,15 +240,6 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
           c4 -= wrap ? upk : 0;
           kk += wrap;
         }
-#if SPS_A_QUAD && !defined(SPS_ABLATE_A)
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          va[g].x = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].x);
-          va[g].y = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].y);
-          va[g].z = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].z);
-          va[g].w = (uint32_t)__builtin_amdgcn_ds_bpermute(xsrc, (int)va[g].w);
-        }
-#endif
 #if defined(SPS_ABLATE_MFMA)
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -555,215 +531,6 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
         if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * esc + esh, 0.f);
       }
     }
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// Row-compacting sparse convolution (3x3x3x3 layers of the fine levels).
-//   k_conv above executes an MFMA row slot for every (16-row tile, present offset) pair although only
-//   43..56 % of the tile's rows have that neighbour (tools/compaction_stats.py).  Here one workgroup
-//   owns a 64-row SUPERTILE with lane = row: for an offset k, a ballot compacts the rows that have the
-//   neighbour into ceil(c/16) MFMA row slots (1.77x fewer slots at level 0, 1.5x at level 1), only those
-//   rows are gathered, and one weight fragment serves up to 64 rows.  The products are added into
-//   LDS accumulators owned by the issuing wave (ds_add_f32, single writer -> deterministic).  The 4 waves
-//   take interleaved quarters of the supertile's offset list; their partials are summed in fixed order
-//   in the epilogue (BN / residual branch / ReLU / `final` fused as in k_conv).
-// ------------------------------------------------------------------------------------------
-
-template <int NTW, int KB, int MINW, bool DS, bool FIN>
-__global__ __launch_bounds__(256, MINW) void k_conv_sc(ConvArgs a) {
-  // row 64 of acc_s / slots 64..127 of the lists are dummies: predicated-off lanes write there, so the
-  // hot loops are free of divergent branches (hipcc otherwise waits after every conditional load)
-  __shared__ float acc_s[4][65][NTW * 16];
-  __shared__ uint32_t loff_s[4][KB][128];
-  __shared__ unsigned char lrow_s[4][KB][128];
-  __shared__ unsigned char klist_s[4][128];
-  const int count = *a.n_out;
-  const int nst = (count + 63) >> 6;
-  const int ntile_total = (count + 15) >> 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsA2 =
-      __builtin_amdgcn_make_buffer_rsrc((void *)(DS ? a.in2 : a.in), 0, (int)(DS ? a.in2_bytes : a.in_bytes), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsM =
-      __builtin_amdgcn_make_buffer_rsrc((void *)a.tmask, 0, ntile_total * 16, 0x00020000);
-  const uint32_t ldn32 = (uint32_t)a.ldn;
-  const int upk = a.upk;
-  const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
-  const uint32_t wunit = (uint32_t)a.NT * 256u;
-  const uint32_t wlane = (uint32_t)r * 16u;
-  unsigned char *kl = klist_s[wave];
-  float(*acc)[NTW * 16] = acc_s[wave];
-  const unsigned long long lt = (1ull << lane) - 1ull;
-
-  for (int st = blockIdx.x; st < nst; st += gridDim.x) {
-    const int row0 = st * 64;
-    const int row = row0 + lane;
-    const bool rv = row < count;
-    // ---- masks: this lane's tile (4 words; tiles beyond the end read as 0) and the union over the
-    //      supertile's 4 tiles -> compact offset list
-    const u32x4 twv = __builtin_amdgcn_raw_buffer_load_b128(rsM, (uint32_t)((row0 >> 4) + q) * 16u, 0, 0);
-    const uint32_t tw0 = twv.x, tw1 = twv.y, tw2 = twv.z;
-    uint32_t un[4] = {twv.x, twv.y, twv.z, twv.w};
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      un[w] |= __shfl_xor(un[w], 16, 64);
-      un[w] |= __shfl_xor(un[w], 32, 64);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const bool b0 = (((lane < 32 ? un[0] : un[1]) >> (lane & 31)) & 1u) != 0u;
-    const bool b1 = (((lane < 32 ? un[2] : un[3]) >> (lane & 31)) & 1u) != 0u;
-    const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
-    const int n0 = __popcll(bal0);
-    kl[b0 ? __popcll(bal0 & lt) : 127] = (unsigned char)lane;                 // slot 127: dummy
-    kl[b1 ? n0 + __popcll(bal1 & lt) : 127] = (unsigned char)(lane + 64);
-    const int nk = n0 + __popcll(bal1);
-    // ---- zero this wave's accumulators (consecutive lanes -> consecutive words: conflict-free)
-#pragma unroll
-    for (int e = 0; e < NTW * 16; ++e) {
-      const int id = e * 64 + lane;
-      acc[id / (NTW * 16)][id % (NTW * 16)] = 0.f;
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    // ---- this wave's offsets: list entries wave, wave + 4, ...   (+ the fused residual branch on wave 0)
-    const int nmine = nk > wave ? (nk - wave + 3) >> 2 : 0;
-    const int nextra = (DS && wave == 0) ? 1 : 0;  // virtual offset: x[row] @ Wds with every row present
-    for (int jb = 0; jb < nmine + nextra; jb += KB) {
-      // stage KB offsets: neighbour rows -> ballot -> compacted byte offsets + original rows
-      int kk[KB], cnt[KB];
-      int idx[KB];
-#pragma unroll
-      for (int b = 0; b < KB; ++b) {
-        const int j = jb + b;
-        const int k = (int)kl[min(wave + 4 * j, 126)];
-        kk[b] = j < nmine ? k : -1;  // -1: the residual branch (or nothing)
-        const uint32_t w = k < 32 ? tw0 : (k < 64 ? tw1 : tw2);
-        const bool has = j < nmine && rv && ((w >> (k & 31)) & 1u);
-        const uint32_t off = has ? ((uint32_t)k * ldn32 + (uint32_t)row) * 4u : OOR;
-        const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
-        idx[b] = has ? v : -1;
-      }
-#pragma unroll
-      for (int b = 0; b < KB; ++b) {
-        const int j = jb + b;
-        const bool extra = DS && nextra && j == nmine;
-        const bool pr = extra ? rv : idx[b] >= 0;
-        const unsigned long long bal = __ballot(pr);
-        cnt[b] = __popcll(bal);
-        const int rk = pr ? __popcll(bal & lt) : 64 + lane;
-        loff_s[wave][b][rk] = extra ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) : (uint32_t)idx[b] * ldi4;
-        lrow_s[wave][b][rk] = (unsigned char)lane;
-      }
-      __builtin_amdgcn_wave_barrier();
-      // process the batch: chunk level ch (16 compacted rows each), all staged offsets together
-      int maxc = 0;
-#pragma unroll
-      for (int b = 0; b < KB; ++b) maxc = max(maxc, cnt[b]);
-      for (int ch = 0; ch * 16 < maxc; ++ch) {
-        floatx4 d[KB][NTW];
-#pragma unroll
-        for (int b = 0; b < KB; ++b)
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) d[b][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-        uint32_t abase[KB], wbase[KB];
-        int nu[KB];  // units of the item in this chunk (0 = nothing to do)
-        int gmax = 0;
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-          const int j = jb + b;
-          const bool extra = DS && nextra && j == nmine;
-          const int slot = ch * 16 + r;
-          const uint32_t lo = loff_s[wave][b][slot];
-          abase[b] = slot < cnt[b] ? lo : OOR;
-          const int ku = extra ? a.K * upk : kk[b] * upk;  // first unit of the offset in Wu
-          wbase[b] = (uint32_t)ku * wunit + wlane;
-          nu[b] = ch * 16 < cnt[b] ? (extra ? a.upk2 : upk) : 0;
-          gmax = max(gmax, (nu[b] + 3) >> 2);
-        }
-        for (int gg = 0; gg < gmax; ++gg) {
-          u32x4 va[KB];
-          u32x4 vb[KB][NTW];
-          const int c4 = 4 * gg + q;
-#pragma unroll
-          for (int b = 0; b < KB; ++b) {
-            const int j = jb + b;
-            const bool extra = DS && nextra && j == nmine;
-            const bool on = c4 < nu[b];
-            const uint32_t oa = on ? abase[b] + (uint32_t)c4 * 16u : OOR;
-            const uint32_t ob = on ? wbase[b] + (uint32_t)c4 * wunit : OOR;
-            va[b] = (DS && extra) ? __builtin_amdgcn_raw_buffer_load_b128(rsA2, oa, 0, 0)
-                                  : __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) vb[b][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
-          }
-          // out-of-range operands are zeros: the MFMAs of exhausted items add nothing (no branch)
-#pragma unroll
-          for (int b = 0; b < KB; ++b) {
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].x), __uint_as_float(vb[b][nt].x), d[b][nt], 0, 0, 0);
-              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].y), __uint_as_float(vb[b][nt].y), d[b][nt], 0, 0, 0);
-              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].z), __uint_as_float(vb[b][nt].z), d[b][nt], 0, 0, 0);
-              d[b][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[b].w), __uint_as_float(vb[b][nt].w), d[b][nt], 0, 0, 0);
-            }
-          }
-        }
-        // scatter-add the chunk's results to the rows they belong to (D map: col = r, row slot = q*4 + i).
-        // Plain read-add-write: this wave is the only writer of acc, a row occurs once per item, and LDS
-        // operations of a wave execute in order (ds_add_f32 costs ~190 LDS cycles per instruction here).
-        // The four row bytes of a lane are one aligned 32-bit read; slots beyond cnt go to dummy row 64.
-#pragma unroll
-        for (int b = 0; b < KB; ++b) {
-          const uint32_t rows4 = *reinterpret_cast<const uint32_t *>(&lrow_s[wave][b][ch * 16 + q * 4]);
-          float *dst[4];
-          float cur[4][NTW];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int slot = ch * 16 + q * 4 + i;
-            const int orow = slot < cnt[b] ? (int)((rows4 >> (8 * i)) & 0xFFu) : 64;
-            dst[i] = &acc[orow][r];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) cur[i][nt] = dst[i][nt * 16];
-          }
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) dst[i][nt * 16] = cur[i][nt] + d[b][nt][i];
-          __builtin_amdgcn_wave_barrier();
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    // ---- epilogue: sum the 4 waves' partials in fixed order, BN shift/scale, residual, ReLU, store
-#pragma unroll
-    for (int e = 0; e < NTW * 4; ++e) {
-      const int id = e * 256 + threadIdx.x;
-      const int rr = id / (NTW * 16), col = id % (NTW * 16);
-      const int ro = row0 + rr;
-      const float sum = ((acc_s[0][rr][col] + acc_s[1][rr][col]) + acc_s[2][rr][col]) + acc_s[3][rr][col];
-      const bool cv = col < a.cout;
-      float y = 0.f;
-      if (cv) {
-        y = sum * a.scale[col] + a.shift[col];
-        if (a.res && ro < count) y += a.res[(size_t)ro * a.ldr + col];
-        if (a.relu) y = fmaxf(y, 0.f);
-        if (ro < count) a.out[(size_t)ro * a.ldo + col] = y;
-      }
-      if (FIN && NTW == 1) {  // `final`: 16 consecutive threads hold one row
-        float t = cv ? y * a.fin_w[col] : 0.f;
-        t += __shfl_xor(t, 1, 64);
-        t += __shfl_xor(t, 2, 64);
-        t += __shfl_xor(t, 4, 64);
-        t += __shfl_xor(t, 8, 64);
-        if ((threadIdx.x & 15) == 0 && ro < count) a.fin_out[ro] = t + a.fin_b;
-      }
-    }
-    __syncthreads();
   }
 }
 

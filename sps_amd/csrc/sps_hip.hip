@@ -24,7 +24,7 @@
 //                 present-offset mask per 16-row tile
 //   features    : row-major f32 [V, C]; concatenations are strided views of one buffer (ME.cat costs nothing)
 // Diagnostic environment hooks (never needed in product use): SPS_GEOM_L<l>, SPS_CONV_MAX_WG,
-// SPS_SC_LEVELS, SPS_DIAG_SKIP; compile-time SPS_ABLATE_* (tools/ablate*.sh).
+// SPS_DIAG_SKIP, SPS_NO_MERGE, SPS_GRID_SCALE; compile-time SPS_ABLATE_* (tools/ablate*.sh).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -507,33 +507,6 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     }
   }
   const bool ds = cs.ds_cin > 0;
-  // EXPERIMENT, off by default: on MI355X the row-compacting kernel is slower than k_conv (block8.conv1
-  // 61 vs 44 us, block7.conv1 42 vs 33 us): its 1.5-1.8x fewer MFMA row slots are outweighed by the LDS
-  // traffic of the per-offset compaction lists + read-add-write accumulation and by 104 VGPRs (4 waves
-  // per SIMD).  SPS_SC_LEVELS=<l> enables it for levels 0..l (parity tests pass with it).
-  static const int sc_levels = [] { const char *e = getenv("SPS_SC_LEVELS"); return e ? atoi(e) : -1; }();
-  if (cs.K == 81 && cc.level_out <= sc_levels && a.NT <= 2) {
-    // row-compacting kernel: one workgroup per 64-row supertile
-    a.S = 1;
-    int64_t gs = (c->cap / 64) >> cc.level_out;
-    if (gs < 64) gs = 64;
-    if (gs > 4096) gs = 4096;
-    const dim3 gr((unsigned)gs);
-    if (a.NT == 1) {
-      if (cc.fin)
-        hipLaunchKernelGGL((k_conv_sc<1, 4, 4, true, true>), gr, dim3(256), 0, st, a);
-      else if (ds)
-        hipLaunchKernelGGL((k_conv_sc<1, 4, 4, true, false>), gr, dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL((k_conv_sc<1, 4, 4, false, false>), gr, dim3(256), 0, st, a);
-    } else {
-      if (ds)
-        hipLaunchKernelGGL((k_conv_sc<2, 2, 4, true, false>), gr, dim3(256), 0, st, a);
-      else
-        hipLaunchKernelGGL((k_conv_sc<2, 2, 4, false, false>), gr, dim3(256), 0, st, a);
-    }
-    return SPS_OK;
-  }
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
   if (g.S > 1 && g.ntw != 1) return fail(SPS_ERR_INVALID, "split-K needs one column tile per wave");
   if (g.S == 4) {
