@@ -188,7 +188,8 @@ int sps_get_parent(sps_ctx *ctx, int level, int32_t *parent_dev);
  * level 0.  pairs_host[k] = number of (in,out) pairs of offset k (81 or 125 entries). */
 int sps_get_map_pairs(sps_ctx *ctx, int which, int64_t *pairs_host);
 /* Present-offset masks of the 16-row output tiles of a kernel map (which as above): uint32
- * [n_tiles][4]; bit k set = some row of the tile has a neighbour through offset k. */
+ * [n_tiles][4].  which = 0..4 (3x3x3x3): one word per time slice, offset k = 27 * word + bit (word 3 unused);
+ * which = 5: bit k of the 128-bit field.  A set bit = some row of the tile has a neighbour through offset k. */
 int sps_get_tile_masks(sps_ctx *ctx, int which, uint32_t *masks_dev, int64_t *n_tiles);
 /* The 3x3x3x3 neighbour table of level `which` (0..4), int32 [81][V] compact; entries of (tile, k)
  * pairs whose tile-mask bit is clear are unspecified (never written, never read by the convolution). */

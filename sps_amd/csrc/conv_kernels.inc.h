@@ -141,12 +141,14 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
         w0 = m[lane >> 5];
         w1 = m[2 + (lane >> 5)];
       }
-      const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = (w1 >> (lane & 31)) & 1u;
+      // mask word w holds offsets 27 w .. 27 w + 26 (3x3x3x3: one word per time slice; the 8-offset stride maps
+      // only use word 0); word 3 is never written
+      const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = lane < 32 && ((w1 >> (lane & 31)) & 1u);
       const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
       const unsigned long long lt = (1ull << lane) - 1ull;
       const int n0 = __popcll(bal0);
-      if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)lane;
-      if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(lane + 64);
+      if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)((lane >> 5) * 27 + (lane & 31));
+      if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(54 + lane);
       nk = n0 + __popcll(bal1);
     } else if (lane == 0) {
       kl[0] = 0;

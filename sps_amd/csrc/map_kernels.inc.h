@@ -83,10 +83,11 @@ __device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int
 // nbr[k*ldn + u] = row of the voxel at (coordinate of u) + offset_k, or -1   (App. A.6-A.8)
 //   3x3x3x3 (all levels): k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1); blockIdx.y = (dy,dz,dt) combo
 // offsets are in units of the level's stride (the block grid already is).
-// One thread per row walks all 27 (dy,dz,dt) runs of three dx neighbours.  The 81-bit present-offset mask of
-// a 16-row tile is assembled in registers from ballots (every lane of the tile's 16-lane group holds the same
-// words) and written with ONE plain 16-byte store: no atomics, and the mask words need no zero fill.
-__device__ inline void build_nbr3(const MapsArgs &a, int bid) {
+// One thread per (row, time slice) walks the 9 (dy,dz) runs of three dx neighbours of that slice.  The
+// present-offset mask of a 16-row tile has one 32-bit WORD PER TIME SLICE (word dt+1, bit (dx+1)+3(dy+1)+9(dz+1);
+// offset k = 27 * word + bit), assembled in registers from ballots (every lane of the tile's 16-lane group holds
+// the same word) and written with one plain store: no atomics, and the mask words need no zero fill.
+__device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   int local;
   const int l = level_of_chunk(a, 0, local, bid);
   const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
@@ -102,16 +103,16 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid) {
     const int r = ok ? L.vblock[u] : 0;
     const int bit = ok ? L.vbit[u] : 0;
     const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
-    const int *__restrict__ adj = L.badj + (size_t)r * 81;
-    uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
+    const int *__restrict__ adj = L.badj + (size_t)r * 81 + slice * 27;
+    // the run x = px-1 .. px+1 touches the block at offset 0 and at most one of the blocks at -1 / +1
+    const int side = px == 0 ? -1 : (px == 3 ? 1 : 0);
+    uint32_t m = 0u;
 #pragma unroll 3
-    for (int c = 0; c < 27; ++c) {
-      const int dy = c % 3 - 1, dz = (c / 3) % 3 - 1, dt = c / 9 - 1;
+    for (int c = 0; c < 9; ++c) {
+      const int dy = c % 3 - 1, dz = c / 3 - 1;
       const int ty = py + dy, tz = pz + dz;
-      const int ad0 = (dt + 1) * 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
+      const int ad0 = ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
       const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
-      // the run x = px-1 .. px+1 touches the block at offset 0 and at most one of the blocks at -1 / +1
-      const int side = px == 0 ? -1 : (px == 3 ? 1 : 0);
       const int nb_c = ok ? adj[ad0] : -1;
       const int nb_s = (ok && side != 0) ? adj[ad0 + side] : -1;
       const unsigned long long mk_c = nb_c >= 0 ? L.bmask[nb_c] : 0ull;
@@ -127,19 +128,22 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid) {
         const int nbit = nbit0 | (tx & 3);
         int row = -1;
         if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
-        const int k = 3 * c + dx + 1;
+        const int j = 3 * c + dx + 1;  // bit inside the slice word
         const unsigned long long bal = __ballot(row >= 0);
         const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
         // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
-        if (any && ok) nbr[(size_t)k * ldn + u] = row;
-        const uint32_t b = any ? 1u << (k & 31) : 0u;
-        m0 |= (k >> 5) == 0 ? b : 0u;
-        m1 |= (k >> 5) == 1 ? b : 0u;
-        m2 |= (k >> 5) == 2 ? b : 0u;
+        if (any && ok) nbr[(size_t)(27 * slice + j) * ldn + u] = row;
+        m |= any ? 1u << j : 0u;
       }
     }
-    if ((lane & 15) == 0 && ok) *reinterpret_cast<uint4 *>(tmask + (size_t)(u >> 4) * 4) = make_uint4(m0, m1, m2, 0u);
+    if ((lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = m;
   }
+}
+
+// bit test of a tile mask: 3x3x3x3 maps keep one word per time slice, every other map bit k of the 128-bit field
+__device__ inline bool tile_mask_test(const uint32_t *__restrict__ tmask, int u, int k, bool slice_words) {
+  const int w = slice_words ? k / 27 : k >> 5, b = slice_words ? k - 27 * w : k & 31;
+  return (tmask[(size_t)(u >> 4) * 4 + w] >> b) & 1u;
 }
 
 //   5x5x5x1 (level 0): k = (dx+2) + 5(dy+2) + 25(dz+2); blockIdx.y = (dy,dz) combo
@@ -207,25 +211,25 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
   }
 }
 
-// Kernel maps of all levels in ONE launch: workgroups [0, n_nbr) build the 3x3x3x3 neighbour tables (256 rows
-// each, all 81 offsets), the rest the stride maps (down / up) of the four level pairs.
+// Kernel maps of all levels in ONE launch: workgroups [0, n_nbr = 3 * nchunk) build the 3x3x3x3 neighbour tables
+// (256 rows of one time slice each: chunk = bid % nchunk, slice = bid / nchunk), the rest the stride maps (down / up) of the four level pairs.
 // (conv0, which also only needs the block structure, stays a launch of its own: merged in here it costs the map
 //  part two waves of occupancy and overlaps with nothing: 63 us merged vs 59 us apart)
-__global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int n_nbr) {
+__global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int nchunk, int n_nbr) {
   const int bid = (int)blockIdx.x;
   if (bid < n_nbr)
-    build_nbr3(ma, bid);
+    build_nbr3(ma, bid % nchunk, bid / nchunk);
   else
     build_stride_maps(ma, bid - n_nbr);
 }
 
-__global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, const int *__restrict__ n_ptr,
+__global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slice_words, const int *__restrict__ n_ptr,
                               const uint32_t *__restrict__ tmask, unsigned long long *__restrict__ pairs) {
   const int n = *n_ptr;
   const int k = blockIdx.y;
   int c = 0;
   for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
-    if ((tmask[(size_t)(u >> 4) * 4 + (k >> 5)] >> (k & 31)) & 1u)  // entries of absent (tile, k) are never written
+    if (tile_mask_test(tmask, u, k, slice_words != 0))  // entries of absent (tile, k) are never written
       c += nbr[(size_t)k * ldn + u] >= 0;
   for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pairs[k], (unsigned long long)c);

@@ -331,7 +331,7 @@ int reserve(sps_ctx *c, int64_t n) {
   c->cap = cap;
   c->hcap = hcap;
   c->last_n = 0;
-  HIP_TRY(hipMemset(c->zero_region, 0, c->zero_bytes));
+  HIP_TRY(hipMemset(c->zero_region, 0, (16 + (size_t)(cap / 16) * 4 * 10) * sizeof(uint32_t)));  // counters + every mask word once
   return SPS_OK;
 }
 
@@ -889,10 +889,10 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   ma.ldn = cap;
   // (the 5x5x5x1 map is never materialised: conv0 is fused with it, k_conv0_fused)
   if (no_merge & 4) {
-    hipLaunchKernelGGL(k_maps, dim3(off), dim3(256), 0, st, ma, off);
-    hipLaunchKernelGGL(k_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, 0);
+    hipLaunchKernelGGL(k_maps, dim3(off * 3), dim3(256), 0, st, ma, off, off * 3);
+    hipLaunchKernelGGL(k_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, 0);
   } else {
-    hipLaunchKernelGGL(k_maps, dim3(off + ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off);
+    hipLaunchKernelGGL(k_maps, dim3(off * 3 + ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, off * 3);
   }
   c->diag_have_state = true;
   }  // !skip_front
@@ -1244,7 +1244,7 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
     hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0,
                        c->lv[0].view(), c->nbr5, c->cap, c->tm5);
   HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, c->cap,
+  hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, c->cap, which == 5 ? 0 : 1,
                      c->counts + level, which == 5 ? c->tm5 : c->lv[which].tm3, c->pairs);
   unsigned long long h[128];
   HIP_TRY(hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost));

@@ -22,10 +22,12 @@ full = np.full((81, ldn), -1, np.int32)
 full[:, :V] = nbr.cpu().numpy()
 # entries whose (tile, k) mask bit is clear are never written by the map builder: make them -1
 mm = m.cpu().numpy().view(np.uint32)
-bits = np.unpackbits(mm.view(np.uint8), axis=1, bitorder="little")[:, :81].astype(bool)   # [tiles, 81]
+allbits = np.unpackbits(mm.view(np.uint8), axis=1, bitorder="little").astype(bool)        # [tiles, 128]
+bits = allbits[:, [32 * (k // 27) + k % 27 for k in range(81)]]                               # one word per time slice
 full = np.where(np.repeat(bits.T, 16, axis=1)[:, :ldn], full, -1)
 with open("/tmp/nbr.bin", "wb") as f:
     np.array([V, ldn, n.value], np.int64).tofile(f)
     full.astype(np.int32).tofile(f)
-    mm.tofile(f)
+    packed = np.zeros((len(mm), 128), bool); packed[:, :81] = bits
+    np.packbits(packed, axis=1, bitorder="little").view(np.uint32).tofile(f)   # contiguous 81-bit layout for gather_replay
 print("level", level, "V", V, "tiles", n.value, "pairs", int((full >= 0).sum()))
