@@ -101,8 +101,6 @@ int fail(int code, const char *fmt, ...) {
 // ------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_SPLIT = 4;  // split-K lives inside a 4-wave workgroup
-
 inline int64_t next_pow2(int64_t v) {
   int64_t p = 1;
   while (p < v) p <<= 1;
@@ -395,17 +393,11 @@ struct Geometry {
 Geometry conv_geometry(int level, int K, int cin, int nt) {
   if (K == 8 && level >= 3) return {1, 4};  // stride convs into the two coarsest levels: ~100-300 tiles, split four ways
   if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
-  const int upk = cin / 4;  // ~30 present offsets x upk units per tile
-  Geometry g;
-  switch (level) {
-    case 0: g = {nt, 1}; break;
-    case 1: g = {nt, 1}; break;
-    // levels 2-4: few tiles, each wave a chain of dependent load -> MFMA rounds: four splits per tile (one workgroup,
-    // LDS reduction) shorten the chain; serial 0.552 -> 0.506 ms, pipelined throughput unchanged
-    case 2: g = {1, 4}; break;
-    case 3: g = {1, 4}; break;
-    default: g = {1, 4}; break;
-  }
+  (void)cin;
+  // levels 0-1: thousands of tiles, one wave per tile and all its column tiles.  Levels 2-4: few tiles, each wave a
+  // chain of dependent load -> MFMA rounds: one column tile per wave and four splits per tile (one workgroup, LDS
+  // reduction) shorten the chain; serial 0.552 -> 0.506 ms, pipelined throughput unchanged
+  Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{1, 4};
   // tuning hook (diagnostics): SPS_GEOM_L<level>="<full>,<S>"  full=1 -> one wave owns all column tiles
   char name[32];
   snprintf(name, sizeof name, "SPS_GEOM_L%d", level);
