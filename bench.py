@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank control flow on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused-metrics", action="store_true",
+                    help="forward and metric sums as two native calls (sps_forward + sps_metrics_dev) instead of sps_forward_metrics")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -120,9 +122,12 @@ def main():
         """One scan: SPSNet.forward (HIP path) + metric sums into this scan's device row, on stream i mod S."""
         st = streams[i % S]
         with torch.cuda.stream(st):
-            scores = net(batch)
-            ctxs[i % S].metrics_dev(scores.data_ptr(), batch.data_ptr(), batch.stride(0), n_points, eps, 1,
-                                    rows[i % max(K, 1)].data_ptr(), st.cuda_stream)
+            if args.unfused_metrics:
+                scores = net(batch)
+                ctxs[i % S].metrics_dev(scores.data_ptr(), batch.data_ptr(), batch.stride(0), n_points, eps, 1,
+                                        rows[i % max(K, 1)].data_ptr(), st.cuda_stream)
+            else:
+                scores, _ = net.forward_metrics(batch, 1, rows[i % max(K, 1)])
         step_scores[0] = scores
         return scores
 

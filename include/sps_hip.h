@@ -87,6 +87,13 @@ int sps_forward(sps_ctx *ctx, const float *coords_dev, int64_t ld, int64_t n, fl
  * met an unrepresentable coordinate. */
 int sps_check(sps_ctx *ctx, void *stream);
 
+/* Forward + metric sums in one call = one scan of SPSNet.predict_step (reference models.py:84-105): `batch_dev` rows
+ * are (b,x,y,z,t,label,...) as BacchusModule.collate_fn builds them (ld >= 6); scores_dev [n] as sps_forward,
+ * out_dev [n_batches][8] doubles as sps_metrics_dev.  The sums are accumulated by the forward's last kernel while it
+ * produces the scores (no separate fill / metrics launches, no second pass over the scores). */
+int sps_forward_metrics(sps_ctx *ctx, const float *batch_dev, int64_t ld, int64_t n, float voxel_size, float eps,
+                        int n_batches, float *scores_dev, double *out_dev, void *stream);
+
 /* ---- baseline heads on the same backbone ------------------------------
  * The two baselines the reference ships run the SAME CustomMinkUNet14 wiring:
  *   4DMOS  : MOS4DNet.forward  (reference c_ws/src/mos4d/scripts/mos4d.py:11-32) --

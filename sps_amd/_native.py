@@ -38,6 +38,7 @@ def _load() -> C.CDLL:
         "sps_weights_numel": (i64, []),
         "sps_weights_load": (i32, [vp, vp, i64]),
         "sps_forward": (i32, [vp, vp, i64, i64, f32, vp, vp]),
+        "sps_forward_metrics": (i32, [vp, vp, i64, i64, f32, f32, i32, vp, vp, vp]),
         "sps_head_num_tensors": (i32, [i32]),
         "sps_head_tensor_info": (i32, [i32, i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
         "sps_head_numel": (i64, [i32]),
@@ -76,7 +77,7 @@ def _load() -> C.CDLL:
 lib = _load()
 EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
-           "sps_forward", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
+           "sps_forward", "sps_forward_metrics", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
            "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_radius_grid_upload", "sps_radius_count",
@@ -134,6 +135,10 @@ class Context:
                      out_ptr: int, ldo: int, activation: int, stream: int):
         check(lib.sps_forward_head(self.handle, coords_ptr, ld, n, voxel_size, feats_ptr, t_base, out_ptr, ldo,
                                    activation, stream))
+
+    def forward_metrics(self, batch_ptr: int, ld: int, n: int, voxel_size: float, eps: float, n_batches: int,
+                        scores_ptr: int, out_ptr: int, stream: int):
+        check(lib.sps_forward_metrics(self.handle, batch_ptr, ld, n, voxel_size, eps, n_batches, scores_ptr, out_ptr, stream))
 
     def forward(self, coords_ptr: int, ld: int, n: int, voxel_size: float, scores_ptr: int, stream: int):
         check(lib.sps_forward(self.handle, coords_ptr, ld, n, voxel_size, scores_ptr, stream))

@@ -4,32 +4,50 @@
 // ------------------------------------------------------------------------------------------
 // metrics (models.py:84-105, util.py:285-299): per batch index accumulators over scan rows
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_metrics(const float *__restrict__ scores, const float *__restrict__ batch, int64_t ld, int n,
-                          float eps, int n_batches, double *__restrict__ acc) {
-  // Few workgroups, each thread accumulates its rows in registers; a thread flushes early only when
-  // the batch index of its rows changes (rows are grouped by b), so the 8 accumulators of a batch
-  // index see ~one atomic per workgroup instead of one per 256 rows.
+struct MetricsArgs {
+  const float *batch;  // rows (b, x, y, z, t, label, ...), row stride ld
+  int64_t ld;
+  float eps;
+  int n_batches;
+  double *acc;         // [n_batches][8], zero before the kernel; null = no metrics (k_tail only)
+};
+
+// Workgroup `bid` of `nb`: per-batch-index accumulation over the scan rows it visits (grid-stride over n points).
+// SLICE = true also produces the scores (slice + sigmoid, models.py:28-29) it then scores against the labels -- the
+// fused tail of sps_forward_metrics; SLICE = false reads them from `scores` (sps_metrics*).
+// Few workgroups, each thread accumulates its rows in registers; a thread flushes early only when the batch index of
+// its rows changes (rows are grouped by b), so the 8 accumulators of a batch index see ~one atomic per workgroup.
+template <bool SLICE>
+__device__ inline void metrics_body(float *__restrict__ scores, const float *__restrict__ logits,
+                                    const int *__restrict__ inv, int n, const MetricsArgs m, int bid, int nb) {
   __shared__ double red[8][4];
   __shared__ int bsh[4];
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int b = -1;
-  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
-    const float *row = batch + (size_t)p * ld;
+  for (int p = bid * (int)blockDim.x + (int)threadIdx.x; p < n; p += nb * (int)blockDim.x) {
+    float s;
+    if (SLICE) {
+      const int vr = inv[p];
+      s = vr >= 0 ? 1.0f / (1.0f + expf(-logits[vr])) : __builtin_nanf("");
+      scores[p] = s;
+    }
+    const float *row = m.batch + (size_t)p * m.ld;
     if (row[4] != 1.0f) continue;  // scan rows only (t == 1)
     const int bi = (int)row[0];
-    if (bi < 0 || bi >= n_batches) continue;
+    if (bi < 0 || bi >= m.n_batches) continue;
     if (bi != b) {
       if (b >= 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          if (v[j] != 0.0) atomicAdd(&acc[b * 8 + j], v[j]);
+          if (v[j] != 0.0) atomicAdd(&m.acc[b * 8 + j], v[j]);
           v[j] = 0.0;
         }
       }
       b = bi;
     }
-    const float s = scores[p], g = row[5];
-    const int pred = s < eps ? 0 : 1, gt = g < eps ? 0 : 1;
+    if (!SLICE) s = scores[p];
+    const float g = row[5];
+    const int pred = s < m.eps ? 0 : 1, gt = g < m.eps ? 0 : 1;
     const double d = (double)s - (double)g;
     v[0] += 1;
     v[1] += (gt == 1 && pred == 1);
@@ -70,13 +88,37 @@ __global__ __launch_bounds__(256) void k_metrics(const float *__restrict__ score
     __syncthreads();
     if (threadIdx.x < 8) {
       const double x = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-      if (x != 0.0) atomicAdd(&acc[wb * 8 + threadIdx.x], x);
+      if (x != 0.0) atomicAdd(&m.acc[wb * 8 + threadIdx.x], x);
     }
   } else if (b >= 0) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-      if (v[j] != 0.0) atomicAdd(&acc[b * 8 + j], v[j]);
+      if (v[j] != 0.0) atomicAdd(&m.acc[b * 8 + j], v[j]);
   }
+}
+
+__global__ __launch_bounds__(256) void k_metrics(float *__restrict__ scores, int n, MetricsArgs m) {
+  metrics_body<false>(scores, nullptr, nullptr, n, m, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// slice + sigmoid of the SPS path and the clean-up of the block hashes in one launch (the last of a forward).
+// With m.acc set (sps_forward_metrics) the gs slice workgroups also accumulate the per-scan metric sums of
+// predict_step (models.py:84-105) for the scores they produce, grid-striding over the points.
+__global__ __launch_bounds__(256) void k_tail(const float *__restrict__ logits, const int *__restrict__ inv, int n,
+                                               float *__restrict__ scores, int gs, PyramidArgs pa, int gb, MetricsArgs m) {
+  if ((int)blockIdx.x >= gs) {  // hash slots used by this forward go back to "free"
+    const int b = (int)blockIdx.x - gs;
+    bhash_cleanup(pa, b / gb, b % gb, gb);
+    return;
+  }
+  if (m.acc) {
+    metrics_body<true>(scores, logits, inv, n, m, (int)blockIdx.x, gs);
+    return;
+  }
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = inv[p];
+  scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
 }
 
 // ------------------------------------------------------------------------------------------

@@ -671,20 +671,6 @@ __global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__r
   scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
 }
 
-// slice + sigmoid of the SPS path and the clean-up of the block hashes in one launch (the last of a forward)
-__global__ __launch_bounds__(256) void k_tail(const float *__restrict__ logits, const int *__restrict__ inv, int n,
-                                               float *__restrict__ scores, int gs, PyramidArgs pa, int gb) {
-  if ((int)blockIdx.x >= gs) {  // hash slots used by this forward go back to "free"
-    const int b = (int)blockIdx.x - gs;
-    bhash_cleanup(pa, b / gb, b % gb, gb);
-    return;
-  }
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n) return;
-  const int v = inv[p];
-  scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
-}
-
 // clean-up alone (head path: its slice kernel is k_slice_head; diagnostics)
 __global__ __launch_bounds__(256) void k_bhash_cleanup(PyramidArgs pa, int gb) {
   bhash_cleanup(pa, (int)blockIdx.x / gb, (int)blockIdx.x % gb, gb);

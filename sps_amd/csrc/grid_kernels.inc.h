@@ -97,8 +97,10 @@ __device__ inline int wave_run_insert(const BHash &h, uint64_t key, bool ok, uin
 __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restrict__ coords, int64_t ld, int n, float vs,
                                                            float t_base, BHash h, int *__restrict__ sslot,
                                                            unsigned char *__restrict__ sbit, int *err,
-                                                           uint4 *__restrict__ zero_region, int zero_vec4) {
+                                                           uint4 *__restrict__ zero_region, int zero_vec4,
+                                                           double *__restrict__ metrics_zero, int metrics_n) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < metrics_n) metrics_zero[p] = 0.0;  // sps_forward_metrics: the sums its tail kernel will accumulate into
   // first kernel of the forward: clears the counters and every tile mask of the previous forward (they stay
   // readable by the introspection getters until then) -- no separate fill launch
   for (int i = p; i < zero_vec4; i += gridDim.x * blockDim.x) zero_region[i] = make_uint4(0u, 0u, 0u, 0u);

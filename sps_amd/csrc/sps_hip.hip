@@ -749,6 +749,10 @@ struct ForwardOpts {
   float t_base = 0.f;
   int64_t ldo = 1;
   int act = 0;                   // 0 = raw logits, 1 = sigmoid
+  // fused metric sums (sps_forward_metrics): coords rows carry the label in column 5
+  double *metrics_out = nullptr;
+  float eps = 0.f;
+  int n_batches = 0;
 };
 
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
@@ -772,6 +776,24 @@ int sps_forward_head(sps_ctx *c, const float *coords, int64_t ld, int64_t n, flo
   fo.ldo = ldo;
   fo.act = activation;
   return forward_impl(c, coords, ld, n, vs, out, fo, stream);
+}
+
+int sps_forward_metrics(sps_ctx *c, const float *batch, int64_t ld, int64_t n, float vs, float eps, int n_batches,
+                        float *scores, double *out_dev, void *stream) {
+  if (c && c->have_weights && c->net->out_channels != 1)
+    return fail(SPS_ERR_INVALID, "the loaded weights have a %d-channel head: use sps_forward_head", c->net->out_channels);
+  if (!out_dev) return fail(SPS_ERR_INVALID, "null argument");
+  if (n_batches < 1 || n_batches > 31) return fail(SPS_ERR_INVALID, "n_batches must be in [1,31]");
+  if (ld < 6) return fail(SPS_ERR_INVALID, "rows must carry (b,x,y,z,t,label): ld >= 6");
+  if (n == 0) {
+    HIP_TRY(hipSetDevice(c ? c->device : 0));
+    HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n_batches * 8 * sizeof(double), (hipStream_t)stream));
+  }
+  ForwardOpts fo;
+  fo.metrics_out = out_dev;
+  fo.eps = eps;
+  fo.n_batches = n_batches;
+  return forward_impl(c, batch, ld, n, vs, scores, fo, stream);
 }
 
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
@@ -824,7 +846,8 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   const unsigned gsb = (unsigned)(cap / SCAN_BLOCK);  // bound for scans over blocks
   // (the first kernel also clears the counters and tile masks of the previous forward)
   hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, fo.t_base, L0.h, L0.sslot, L0.sbit,
-                     c->err, reinterpret_cast<uint4 *>(c->zero_region), (int)(c->zero_bytes / 16));
+                     c->err, reinterpret_cast<uint4 *>(c->zero_region), (int)(c->zero_bytes / 16), fo.metrics_out,
+                     fo.metrics_out ? fo.n_batches * 8 : 0);
   hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   // ---- point rows + (levels 1..4) every coarser level straight from the level-0 blocks, one launch
@@ -938,10 +961,18 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   } else if (skip_front || (no_merge & 8)) {
     hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)gs), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores);
     if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
+    if (fo.metrics_out) {  // diagnostics paths: the unfused sequence
+      HIP_TRY(hipMemsetAsync(fo.metrics_out, 0, (size_t)fo.n_batches * 8 * sizeof(double), st));
+      hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, scores, (int)n,
+                         MetricsArgs{coords, ld, fo.eps, fo.n_batches, fo.metrics_out});
+    }
   } else {
     // slice + sigmoid and the hash clean-up, one launch
-    hipLaunchKernelGGL(k_tail, dim3((unsigned)(gs + gbc * NLV)), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores, gs,
-                       pa, gbc);
+    // (with fused metrics the slice part is a persistent grid: few workgroups, register accumulation)
+    const MetricsArgs mt{coords, ld, fo.eps, fo.n_batches, fo.metrics_out};
+    const int gst = fo.metrics_out ? grid_for(n, 1024, 128) : gs;
+    hipLaunchKernelGGL(k_tail, dim3((unsigned)(gst + gbc * NLV)), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores, gst,
+                       pa, gbc, mt);
   }
   prof_mark(c, "tail", st);
   HIP_TRY(hipGetLastError());
@@ -994,8 +1025,8 @@ int sps_metrics(sps_ctx *c, const float *scores, const float *batch, int64_t ld,
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(c->macc, 0, (size_t)n_batches * 8 * sizeof(double), st));
   if (n > 0)
-    hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
-                       n_batches, c->macc);
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, const_cast<float *>(scores), (int)n,
+                       MetricsArgs{batch, ld, eps, n_batches, c->macc});
   HIP_TRY(hipMemcpyAsync(out_host, c->macc, (size_t)n_batches * 8 * sizeof(double), hipMemcpyDeviceToHost, st));
   int e = 0;
   HIP_TRY(hipMemcpyAsync(&e, c->err, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1089,8 +1120,8 @@ int sps_metrics_dev(sps_ctx *c, const float *scores, const float *batch, int64_t
   hipStream_t st = (hipStream_t)stream;
   HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n_batches * 8 * sizeof(double), st));
   if (n > 0)
-    hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, scores, batch, ld, (int)n, eps,
-                       n_batches, out_dev);
+    hipLaunchKernelGGL(k_metrics, dim3((unsigned)grid_for(n, 1024, 128)), dim3(256), 0, st, const_cast<float *>(scores), (int)n,
+                       MetricsArgs{batch, ld, eps, n_batches, out_dev});
   HIP_TRY(hipGetLastError());
   return SPS_OK;
 }

@@ -152,6 +152,30 @@ class SPSNet(nn.Module):
         return self.model(batch[:, :5])          # strided view: no copy crosses the boundary
 
     @torch.no_grad()
+    def forward_metrics(self, batch: torch.Tensor, n_batches: int = 1, out: torch.Tensor | None = None):
+        """forward + the per-batch-index metric sums of predict_step in ONE native call (sps_forward_metrics): returns
+        (scores [N], sums float64 [n_batches, 8] on the device).  ``batch`` rows are (b,x,y,z,t,label); ``out`` may be
+        a preallocated contiguous float64 device tensor of n_batches * 8 elements (e.g. a row of a results table)."""
+        _require_device_tensor(batch, "batch")
+        if batch.dim() != 2 or batch.shape[1] < 6:
+            raise ValueError(f"batch must be [N, 6] = (b,x,y,z,t,label), got {tuple(batch.shape)}")
+        if batch.dtype != torch.float32 or batch.stride(1) != 1:
+            batch = batch.to(torch.float32).contiguous()
+        with torch.cuda.device(batch.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            ctx = get_context(batch.device.index or 0, stream)
+            self.model._sync_weights(ctx)
+            n = batch.shape[0]
+            scores = torch.empty(n, dtype=torch.float32, device=batch.device)
+            if out is None:
+                out = torch.empty((n_batches, 8), dtype=torch.float64, device=batch.device)
+            elif out.dtype != torch.float64 or not out.is_contiguous() or out.numel() != n_batches * 8 or not out.is_cuda:
+                raise ValueError("out must be a contiguous float64 device tensor with n_batches * 8 elements")
+            ctx.forward_metrics(batch.data_ptr(), batch.stride(0) if n else 6, n, self.model.voxel_size, float(self.epsilon),
+                                n_batches, scores.data_ptr(), out.data_ptr(), stream)
+        return scores, out
+
+    @torch.no_grad()
     def step_metrics(self, batch: torch.Tensor, scores: torch.Tensor, n_batches: int = 1):
         """Per-batch-index sums [count, TP, FP, FN, TN, sum (s-g)^2, sum g, sum g^2] over scan rows
         (one device->host copy for the whole step; the reference does three, models.py:87,97-98)."""

@@ -475,3 +475,35 @@ def test_structured_stress_cases(net, params, kind):
         # interior voxels of the t = 1 cube see all 27 dt = 0 neighbours
         p = ctx().map_pairs(0)
         assert p[40] == ctx().level_counts()[0] and min(p[27:54]) > 0
+
+
+def test_fused_forward_metrics_matches_separate_calls(net, params):
+    """sps_forward_metrics = sps_forward + sps_metrics_dev: identical scores, identical confusion counts, float sums to
+    rounding (the accumulation order of the f64 atomics differs); also with several batch indices and empty input."""
+    scenes = [synthetic.make_scene(scan_seed=11 + i, n_azimuth=300, batch_index=i)["batch"] for i in range(3)]
+    for nb, arr in ((1, scenes[0]), (3, np.concatenate(scenes, 0))):
+        dev = torch.from_numpy(arr).cuda()
+        s_ref = net(dev)
+        sums_ref = np.asarray(net.step_metrics(dev, s_ref, nb), dtype=np.float64)
+        table = torch.full((2, nb, 8), -1.0, dtype=torch.float64, device="cuda")
+        s_fused, out = net.forward_metrics(dev, nb, table[1])
+        torch.cuda.synchronize()
+        assert out.data_ptr() == table[1].data_ptr() and (table[0] == -1).all()
+        assert torch.equal(s_fused, s_ref)
+        got = out.cpu().numpy()
+        np.testing.assert_array_equal(got[:, :5], sums_ref[:, :5])                 # count, TP, FP, FN, TN
+        np.testing.assert_allclose(got[:, 5:], sums_ref[:, 5:], rtol=1e-12, atol=1e-9)
+        want = O.predict_metrics(s_ref.cpu().numpy(), arr, EPS)
+        m = metrics_from_all(got)
+        for k in ("loss", "r2", "dIoU", "precision", "recall", "f1"):
+            assert abs(m[k] - want[k]) < 1e-9, k
+    s0, out0 = net.forward_metrics(torch.empty((0, 6), device="cuda"), 2)
+    torch.cuda.synchronize()
+    assert s0.shape == (0,) and (out0 == 0).all()
+    with pytest.raises(ValueError, match="N, 6"):
+        net.forward_metrics(torch.zeros((4, 5), device="cuda"))
+
+
+def metrics_from_all(sums):
+    from sps_amd.models.models import metrics_from_sums
+    return metrics_from_sums(np.asarray(sums).sum(axis=0))
