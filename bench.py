@@ -1,27 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- scans/sec of the SPS per-scan hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--config 2|3|4]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the whole hot path over one batch of synthetic input that is already
-resident in HBM: quantise + voxel hash + stride pyramid + kernel maps + the 33 sparse convs of
-CustomMinkUNet14 (fp32) + slice + sigmoid + the per-scan metric sums (written to a device row).
-Workload = BASELINE config 2: one ~100k-point LiDAR-like scan + its variant-B submap at 0.1 m voxels.
-Scans are sharded data-parallel (each rank owns its scans; weak scaling); the only exchange is one
-RCCL all-gather of the per-scan metric rows at the end of the sequence, inside the timed region.
+A "step" is one pass of the whole hot path over one batch of synthetic input that is already resident in HBM:
+quantise + voxel hash + stride pyramid + kernel maps + the 33 sparse convs of CustomMinkUNet14 (fp32) + slice +
+sigmoid + the per-scan metric sums (written to a row of a device table).  It runs through sps_amd.engine.ScanEngine
+-- the same loop scripts/predict.py runs -- with `--streams` independent scans in flight.
+
+  --config 2 (default, the configuration BASELINE.json's metric is quoted on): one ~100k-point LiDAR-like scan +
+             its variant-B submap at 0.1 m voxels per step;
+  --config 3: streamed sequence, batch = 4 consecutive scans per step (collate_fn layout, batch column 0..3);
+  --config 4: NCLT-like, >= 300k active level-0 voxels, 5x map, one scan per step.
+`value` is always scans/s (config 3 processes 4 scans per step).
+
+Everything that is not steady state (arena, weight upload, one forward per context) happens in ScanEngine.prepare()
+before the timed region, whatever --warmup is; streams are clamped to the step count.  After the resident-input
+region a second, separately reported region feeds every step from a pinned HOST buffer (`h2d_inclusive`, SURVEY
+8(d)); it is never `value`.
+
+Scans are sharded data-parallel (each rank owns its scans; weak scaling); the only exchange is one RCCL all-gather of
+the per-scan metric rows at the end of the sequence, inside the timed region.
 
 Prints ONE JSON line on rank 0, including
-  "roofline":     whole-path algorithmic bytes / GPU time per scan (hipEvents on the
-                  launch stream over the timed region) against the 8 TB/s HBM peak, plus the per-stage
-                  breakdown and the dominant kernel stage;
-  "cpu_baseline": the C restatement of the MinkowskiEngine algorithm (oracle/, kind "port") timed on
-                  this box's host cores on a bounded sample of the same workload (rank 0, N = 1 only).
+  "roofline":     whole-path algorithmic bytes / GPU time per step (hipEvents on the launch streams
+                  over the timed region) against the 8 TB/s HBM peak, the per-layer breakdown (hipEvents around every
+                  kernel stage, serial pass) and the dominant kernel with its own roofline fractions;
+  "cpu_baseline": the C restatement of the MinkowskiEngine algorithm (oracle/, kind "port") timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N = 1 only);
+  "parity":       scores / labels / dIoU of the measured path against that oracle on the same input and weights.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
+import math
 import os
 import sys
 import time
@@ -37,6 +52,7 @@ CFG = {
     "MODEL": {"VOXEL_SIZE": 0.1},
     "FILTER": {"THRESHOLD": 0.84},
 }
+KEY_W, KEY_B = "model.MinkUNet.final.kernel", "model.MinkUNet.final.bias"
 
 
 def synthetic_weights(net, seed=0):
@@ -55,23 +71,69 @@ def synthetic_weights(net, seed=0):
     return net
 
 
+def calibrate_final(net, batch, eps, frac=0.3, gain=8.0):
+    """Rescale the `final` 1x1 conv (kernel x gain, bias shifted) so that ~frac of the scan scores are >= eps.  With
+    plain random-init weights no score reaches 0.84, every prediction is "stable" and TP = FP = 0: the uIoU of the
+    metric line would be vacuous.  Synthetic weights are an input of the benchmark, not part of the path."""
+    scores = net(batch)
+    s = scores[batch[:, 4] == 1].double().clamp(1e-9, 1 - 1e-9)
+    sd = net.state_dict()
+    b0 = float(sd[KEY_B].reshape(-1)[0])
+    logits = torch.log(s / (1 - s)) - b0
+    k = max(1, min(len(logits), int(round((1.0 - frac) * len(logits)))))
+    q = float(torch.kthvalue(gain * logits, k).values)
+    sd[KEY_W].mul_(gain)
+    sd[KEY_B].fill_(math.log(eps / (1.0 - eps)) - q)
+    net.model.mark_weights_dirty()
+    return float(sd[KEY_B].reshape(-1)[0])
+
+
+def csrc_sha():
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "sps_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc.h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_workload(config, rank, azimuth, seq_scans, vs):
+    """Returns (list of [N,6] float32 numpy batches that the steps cycle through, n_batches per step, description)."""
+    from sps_amd import synthetic
+    if config == 2:
+        sc = synthetic.make_scene(scan_seed=1 + rank, n_azimuth=azimuth, voxel_size=vs)
+        return [sc["batch"]], 1, ("BASELINE config 2: single ~100k-pt LiDAR-like scan + variant-B submap, 0.1 m voxel, "
+                                  "CustomMinkUNet14 fp32, 1 scan per step per GPU")
+    if config == 3:
+        n = max(4, (seq_scans // 4) * 4)
+        scans = list(synthetic.make_sequence(n, first_seed=100 + 1000 * rank, voxel_size=vs, n_azimuth=azimuth))
+        return [synthetic.collate(scans[i: i + 4]) for i in range(0, n, 4)], 4, (
+            f"BASELINE config 3: streamed sequence ({n} distinct consecutive scans, sensor advancing 0.5 m/scan, cycled), "
+            "batch = 4 scans per step (collate_fn layout), CustomMinkUNet14 fp32")
+    if config == 4:
+        sc = synthetic.make_nclt_scene(seed=5 + rank, voxel_size=vs)
+        return [sc["batch"]], 1, ("BASELINE config 4: NCLT-like scan (3 merged 128-beam scans, 100 m range) + variant-B "
+                                  "submap of a 25-position map, >= 300k active voxels, 1 scan per step per GPU")
+    raise SystemExit("--config must be 2, 3 or 4")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--config", type=int, default=2, help="BASELINE config: 2 (default, the headline), 3 (batch = 4 sequence), 4 (NCLT-like)")
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
-    ap.add_argument("--threads", type=int, default=1,
-                    help="host threads issuing the launches (each owns streams s = t mod threads)")
+    ap.add_argument("--seq-scans", type=int, default=32, help="config 3: distinct scans of the sequence (cycled)")
     ap.add_argument("--streams", type=int, default=23,
-                    help="independent scans in flight per GPU (one HIP stream + native context each); 1 = strictly serial. "
-                         "The HIP runtime multiplexes streams onto 4 hardware queues: counts of the form 4k+3 measure "
-                         "5-15 %% above their neighbours (DESIGN.md section 4), three streams already reach 94 %% of the best")
+                    help="independent steps in flight per GPU (one HIP stream + native context each); 1 = strictly serial. "
+                         "Clamped to --steps.  The HIP runtime multiplexes streams onto 4 hardware queues: counts of the "
+                         "form 4k+3 measure 5-15 %% above their neighbours (DESIGN.md section 4)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank control flow on a single GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused-metrics", action="store_true",
-                    help="forward and metric sums as two native calls (sps_forward + sps_metrics_dev) instead of sps_forward_metrics")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the second (host-buffer-fed) timed region")
+    ap.add_argument("--no-stages", action="store_true", help="skip the per-layer hipEvent pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -96,97 +158,88 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    from sps_amd import roofline, synthetic
-    from sps_amd.models.models import SPSNet, get_context, metrics_from_sums
+    from sps_amd import roofline
+    from sps_amd.engine import ScanEngine
+    from sps_amd.models.models import SPSNet, metrics_from_sums
 
-    # ---- workload: config 2, one scan (+ submap) per rank, seeds differ per rank --------------
+    K, W = max(1, args.steps), max(0, args.warmup)
+    eps = float(CFG["FILTER"]["THRESHOLD"])
+    vs = CFG["MODEL"]["VOXEL_SIZE"]
+
+    # ---- workload (host generation is not timed) ----------------------------------------------------------------
+    batches_np, nb, workload = build_workload(args.config, rank, args.azimuth, args.seq_scans, vs)
+    batches = [torch.from_numpy(b).to(dev) for b in batches_np]
+    pinned = [torch.from_numpy(b).pin_memory() for b in batches_np]
+    max_rows = max(len(b) for b in batches_np)
+    n_points = len(batches_np[0])
+    n_scan = int((batches_np[0][:, 4] == 1).sum())
+
+    # ---- weights: random init of the reference architecture, `final` calibrated so both labels occur -------------
     torch.manual_seed(0)
     net = synthetic_weights(SPSNet(CFG), seed=0).to(dev).eval().freeze()
-    scene = synthetic.make_scene(scan_seed=1 + rank, n_azimuth=args.azimuth)
-    batch_np = scene["batch"]
-    batch = torch.from_numpy(batch_np).to(dev)
-    n_points, n_scan = len(batch_np), scene["n_scan"]
-    S = max(1, args.streams)
-    main_stream = torch.cuda.current_stream()
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else [main_stream]
-    ctxs = [get_context(local, st.cuda_stream) for st in streams]
-    for cx in ctxs:
-        cx.reserve(n_points)
-    ctx = ctxs[0]
-    K, W = args.steps, args.warmup
-    rows = torch.zeros((max(K, 1), 8), dtype=torch.float64, device=dev)      # per-scan metric rows
-    eps = float(CFG["FILTER"]["THRESHOLD"])
-    torch.cuda.synchronize()
+    bias = torch.tensor([calibrate_final(net, batches[0], eps) if rank == 0 else 0.0], dtype=torch.float64, device=dev)
+    if dist is not None:                      # replicated weights: every rank takes rank 0's calibration
+        dist.broadcast(bias, 0)
+        if rank != 0:
+            sd = net.state_dict()
+            sd[KEY_W].mul_(8.0)
+            sd[KEY_B].fill_(float(bias.item()))
+            net.model.mark_weights_dirty()
 
-    def step(i):
-        """One scan: SPSNet.forward (HIP path) + metric sums into this scan's device row, on stream i mod S."""
-        st = streams[i % S]
-        with torch.cuda.stream(st):
-            if args.unfused_metrics:
-                scores = net(batch)
-                ctxs[i % S].metrics_dev(scores.data_ptr(), batch.data_ptr(), batch.stride(0), n_points, eps, 1,
-                                        rows[i % max(K, 1)].data_ptr(), st.cuda_stream)
-            else:
-                scores, _ = net.forward_metrics(batch, 1, rows[i % max(K, 1)])
-        step_scores[0] = scores
-        return scores
-
-    step_scores = [None]
+    # ---- engine: arena + shared weights + one forward per context, all before the timed region -------------------
+    S = max(1, min(args.streams, K))
+    eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb)
+    streams = eng.streams
+    main_stream = eng.main
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
-        step(i)
-    if dist is not None:                      # warm the collective of the timed region (communicator, buffers)
-        dist.all_gather([torch.empty_like(rows) for _ in range(world)], rows)
-    barrier()
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
-    t0 = time.perf_counter()
-    for st, e in zip(streams, ev0):
-        e.record(st)
-    if args.threads > 1:
-        # several host threads issue the launches (ctypes releases the GIL inside libsps_hip.so): thread t owns
-        # the streams s = t mod T, so a stream is only ever touched by one thread
-        import threading
-        T = args.threads
-
-        def worker(t):
-            torch.cuda.set_device(dev)
-            for i in range(K):
-                if (i % S) % T == t:
-                    step(i)
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
-        for x in th:
-            x.start()
-        for x in th:
-            x.join()
-        scores = step_scores[0]
-    else:
+    def timed_region(feed):
+        """W untimed + exactly K timed steps; returns (wall seconds incl. the metric all-gather, GPU ms first start ->
+        last end over all launch streams, gathered rows or None, scores of the last step)."""
+        eng.reset_table(K * nb)
+        for i in range(W):
+            eng.submit(feed[i % len(feed)], nb, row=(i % K) * nb)
+        if dist is not None:                  # warm the collective of the timed region (communicator, buffers)
+            dist.all_gather([torch.empty_like(eng.table) for _ in range(world)], eng.table)
+        barrier()
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in streams]
+        t0 = time.perf_counter()
+        for st, e in zip(streams, ev0):
+            e.record(st)
+        scores = None
         for i in range(K):
-            scores = step(i)
-    for st, e in zip(streams, ev1):
-        e.record(st)
-    gathered = None
-    if dist is not None:                      # the path's one exchange step: per-scan metric rows
-        for st in streams:
-            main_stream.wait_stream(st)
-        gathered = [torch.empty_like(rows) for _ in range(world)]
-        dist.all_gather(gathered, rows)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # GPU time of the timed region: hipEvents on every launch stream, first start -> last end
-    gpu_ms = max(ev0[0].elapsed_time(e1) for e1 in ev1)
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist is not None:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    elapsed = float(el.item())
-    for cx, st in zip(ctxs, streams):
-        cx.check_errors(st.cuda_stream)
-    stream = streams[0]
+            scores = eng.submit(feed[i % len(feed)], nb, row=i * nb)
+        for st, e in zip(streams, ev1):
+            e.record(st)
+        gathered = None
+        if dist is not None:                  # the path's one exchange step: per-scan metric rows
+            for st in streams:
+                main_stream.wait_stream(st)
+            gathered = [torch.empty_like(eng.table) for _ in range(world)]
+            dist.all_gather(gathered, eng.table)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        gpu_ms = max(ev0[0].elapsed_time(e1) for e1 in ev1)     # first start -> last end over the launch streams
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if dist is not None:
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        eng.finish()                          # sticky device errors (coordinate range) surface here
+        return float(el.item()), gpu_ms, gathered, scores
+
+    elapsed, gpu_ms, gathered, scores = timed_region(batches)
+    rows_resident = (torch.cat(gathered, 0) if gathered is not None else eng.table[: K * nb]).cpu().numpy().copy()
+    h2d = None
+    if not args.no_h2d:
+        el2, gpu2, _, _ = timed_region(pinned)
+        h2d = {"value": round(K * nb * world / el2, 2), "unit": "scans/s", "ms_per_step": round(el2 / K * 1e3, 4),
+               "gpu_ms_per_step": round(gpu2 / K, 4), "bytes_per_step": int(batches_np[0].nbytes),
+               "note": "same K steps, every step's [N,6] batch copied from a pinned host buffer on the step's stream "
+                       "inside the timed region (SURVEY 8(d)); never the headline value"}
 
     if rank != 0:
         if dist is not None:
@@ -195,74 +248,84 @@ def main():
         return
 
     # ---- whole-job numbers ------------------------------------------------------------------
-    total_scans = K * world
+    total_scans = K * nb * world
     value = total_scans / elapsed
-    all_rows = torch.cat(gathered, 0) if gathered is not None else rows
-    per_scan = [metrics_from_sums(r) for r in all_rows.cpu().numpy()]
+    per_scan = [metrics_from_sums(r) for r in rows_resident]
     mean_metrics = {k: float(np.mean([m[k] for m in per_scan])) for k in ("loss", "r2", "dIoU", "precision", "recall", "f1")}
+    confusion = {k: float(np.mean([m[k] for m in per_scan])) for k in ("tp", "fp", "fn", "tn")}
 
-    # ---- roofline: algorithmic bytes of THIS run / GPU time per scan --------------------------
+    # ---- roofline: algorithmic bytes of THIS run / GPU time per step --------------------------
+    ctx = eng.ctxs[0]
+    with torch.cuda.stream(streams[0]):
+        net(batches[0])
+    torch.cuda.synchronize()
     V = ctx.level_counts()
     pairs3 = [sum(ctx.map_pairs(l)) for l in range(5)]
     pairs5 = sum(ctx.map_pairs(5))
     work = roofline.algorithmic_work(n_points, V, pairs3, pairs5)
-    t_scan = gpu_ms * 1e-3 / K
-    achieved = work["bytes"] / t_scan / 1e9
-    # per-stage breakdown (separate short pass with stage events; not part of the timed region)
-    ctx.profile_enable(True)
-    acc, reps = {}, 10
-    order = []
-    for _ in range(reps):
-        with torch.cuda.stream(streams[0]):
-            net(batch)
-        for name, ms in ctx.profile_read():
-            if name not in acc:
-                order.append(name)
-            acc[name] = acc.get(name, 0.0) + ms / reps
-    ctx.profile_enable(False)
-    stages = []
-    for name in order:
-        pl = work["per_layer"].get(name)
-        entry = {"stage": name, "ms": round(acc[name], 5)}
-        if pl:
-            entry["alg_gbs"] = round(pl["bytes"] / (acc[name] * 1e-3) / 1e9, 1) if acc[name] > 0 else None
-            entry["alg_tflops"] = round(pl["flops"] / (acc[name] * 1e-3) / 1e12, 2) if acc[name] > 0 else None
-        stages.append(entry)
-    dom = max((s for s in stages if s["stage"] in work["per_layer"]), key=lambda s: s["ms"])
-    # HBM bytes per scan from the committed PMC passes of this build (tools/traffic_pmc.py), if present
+    t_step = gpu_ms * 1e-3 / K
+    achieved = work["bytes"] / t_step / 1e9
+    stages, dom = [], None
+    if not args.no_stages:
+        # per-stage breakdown (separate serial pass with one hipEvent after every kernel stage, on the launch stream)
+        ctx.profile_enable(True)
+        acc, reps, order = {}, 10, []
+        for _ in range(reps):
+            with torch.cuda.stream(streams[0]):
+                net(batches[0])
+            for name, ms in ctx.profile_read():
+                if name not in acc:
+                    order.append(name)
+                acc[name] = acc.get(name, 0.0) + ms / reps
+        ctx.profile_enable(False)
+        for name in order:
+            pl = work["per_layer"].get(name)
+            entry = {"stage": name, "ms": round(acc[name], 5)}
+            if pl and acc[name] > 0:
+                gbs = pl["bytes"] / (acc[name] * 1e-3) / 1e9
+                tf = pl["flops"] / (acc[name] * 1e-3) / 1e12
+                entry.update(alg_bytes=pl["bytes"], alg_gbs=round(gbs, 1), hbm_frac=round(gbs / roofline.HBM_PEAK_GBS, 4),
+                             alg_tflops=round(tf, 2), mfma_f32_frac=round(tf / roofline.MFMA_F32_PEAK_TFLOPS, 4))
+            stages.append(entry)
+        dom = max((s for s in stages if s["stage"] in work["per_layer"]), key=lambda s: s["ms"])
+    # HBM bytes per scan from PMC passes (tools/traffic_pmc.py): only if they were taken with THIS build of the kernels
     traffic, traffic_note = None, "not measured for this build"
     tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp):
+    if os.path.exists(tp) and args.config == 2:
         tj = json.load(open(tp))
-        traffic, traffic_note = tj["hbm_bytes_per_scan"], tj["method"]
+        if tj.get("csrc_sha") == csrc_sha():
+            traffic, traffic_note = tj["hbm_bytes_per_scan"], tj["method"]
+        else:
+            traffic_note = "profiles/traffic.json is stale: it was measured with an earlier build of the kernels"
     roof = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / roofline.HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
-        "kernel": "whole per-scan path (all launches of one forward + metric sums); "
-                  f"{S} independent scans in flight on {S} HIP streams" if S > 1 else
-                  "whole per-scan path (all launches of one forward + metric sums), strictly serial",
-        "alg_bytes_per_scan": work["bytes"], "alg_flops_per_scan": work["flops"],
-        "gpu_ms_per_scan": round(t_scan * 1e3, 4),
+        "kernel": (f"whole per-step path (all launches of one forward + metric sums); {S} independent steps in flight on {S} "
+                   "HIP streams") if S > 1 else "whole per-step path (all launches of one forward + metric sums), strictly serial",
+        "alg_bytes_per_step": work["bytes"], "alg_flops_per_step": work["flops"],
+        "gpu_ms_per_step": round(t_step * 1e3, 4),
         "frac_vs_measured_copy_6290": round(achieved / roofline.HBM_COPY_GBS, 5),
-        "mfma_f32_frac": round(work["flops"] / t_scan / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5),
-        "dominant_stage": dom, "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
+        "mfma_f32_frac": round(work["flops"] / t_step / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5),
+        "dominant_kernel": dom, "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
     }
 
-    # ---- CPU baseline: the oracle's C restatement on this box's host cores (checker only) ----
+    # ---- CPU baseline + parity: the oracle's C restatement on this box's host cores (checker only) ----
     cpu = None
     parity = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import c_oracle
+        from oracle import c_oracle, sps_oracle
         sd = {k.replace("model.MinkUNet.", ""): v.detach().cpu().numpy() for k, v in net.state_dict().items()
               if "num_batches_tracked" not in k}
         blob = c_oracle.pack_blob(sd)
         host_cores = os.cpu_count() or 1
+        batch_np = batches_np[(K - 1) % len(batches_np)]          # the batch of the last timed step
         coords = np.ascontiguousarray(batch_np[:, :5])
-        vs = CFG["MODEL"]["VOXEL_SIZE"]
         # the port's OpenMP loops are fine-grained: on a many-core host more threads is slower, so take
-        # the best of a few thread counts (one scan each) and report the count actually used as `cores`
-        best = None
+        # the best of a few thread counts (one pass each) and report the count actually used as `cores`
+        best, single = None, None
         for th in sorted({t for t in (1, 4, 8, 16, 32, 64) if t <= host_cores}):
+            if args.config != 2 and th == 1:
+                continue
             c_oracle.forward(blob, coords, vs, nthreads=th, want_details=False)
             t = time.perf_counter()
             ref, info = c_oracle.forward(blob, coords, vs, nthreads=th, want_details=False)
@@ -277,28 +340,42 @@ def main():
         for _ in range(nrep):
             c_oracle.forward(blob, coords, vs, nthreads=cores, want_details=False)
         per = (time.perf_counter() - t) / nrep
-        cpu = {"value": round(1.0 / per, 3), "unit": "scans/s", "cores": cores, "kind": "port",
-               "sample": f"{nrep} repeats of the same config-2 scan ({n_points} rows) through the C restatement of the "
-                         f"MinkowskiEngine algorithm (ME itself unavailable), OpenMP with {cores} threads = the fastest of "
+        cpu = {"value": round(nb / per, 3), "unit": "scans/s", "cores": cores, "kind": "port",
+               "sample": f"{nrep} repeats of one step's batch ({len(batch_np)} rows, {nb} scan(s)) through the C restatement of "
+                         f"the MinkowskiEngine algorithm (ME itself unavailable), OpenMP with {cores} threads = the fastest of "
                          f"1/4/8/16/32/64 on this {host_cores}-core host",
-               "single_thread_scans_per_s": round(1.0 / single, 3)}
+               "single_thread_scans_per_s": round(nb / single, 3) if single else None}
         s = scores.cpu().numpy()
         e = np.float32(eps)
         band = np.abs(ref - e) > 1e-5
+        dio_gpu, dio_ref, conf_gpu, conf_ref = [], [], [], []
+        for b in range(nb):
+            r = batch_np[:, 0] == b
+            mo = sps_oracle.predict_metrics(ref[r], batch_np[r], eps)
+            mg = metrics_from_sums(rows_resident[(K - 1) * nb + b])
+            dio_gpu.append(mg["dIoU"])
+            dio_ref.append(mo["dIoU"])
+            scan = batch_np[r][:, 4] == 1
+            pr, gt = ref[r][scan] >= e, batch_np[r][scan, 5].astype(np.float32) >= e
+            conf_ref.append([int((gt & pr).sum()), int((~gt & pr).sum()), int((gt & ~pr).sum()), int((~gt & ~pr).sum())])
+            conf_gpu.append([int(mg["tp"]), int(mg["fp"]), int(mg["fn"]), int(mg["tn"])])
         parity = {"max_abs_score_err_vs_oracle": float(np.max(np.abs(s - ref))),
-                  "label_mismatches_outside_1e-5_band": int(np.sum((s < e)[band] != (ref < e)[band]))}
+                  "label_mismatches_outside_1e-5_band": int(np.sum((s < e)[band] != (ref < e)[band])),
+                  "rows_inside_band": int((~band).sum()),
+                  "unstable_fraction_oracle": float((ref[batch_np[:, 4] == 1] >= e).mean()),
+                  "dIoU_gpu": dio_gpu, "dIoU_oracle": dio_ref,
+                  "confusion_TP_FP_FN_TN_gpu": conf_gpu, "confusion_TP_FP_FN_TN_oracle": conf_ref}
 
     out = {
         "metric": "scans/sec @100k pts, 0.1 m voxel", "value": round(value, 2), "unit": "scans/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE config 2: single ~100k-pt LiDAR-like scan + variant-B submap, 0.1 m voxel, "
-                               "CustomMinkUNet14 fp32, 1 scan per step per GPU",
+        "config": {"workload": workload, "baseline_config": args.config, "scans_per_step": nb,
                    "scan_points": n_scan, "rows": n_points, "voxels_per_level": V,
                    "pairs_3x3x3x3_per_level": pairs3, "pairs_5x5x5x1": pairs5, "sharding": f"dp{world}",
-                   "streams_per_gpu": S},
+                   "streams_per_gpu": S, "final_bias_calibrated": float(bias.item())},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,
-        "host_cores": os.cpu_count(),
+        "mean_confusion": confusion, "h2d_inclusive": h2d, "host_cores": os.cpu_count(),
     }
     print(json.dumps(out))
     if dist is not None:

@@ -70,8 +70,18 @@ int sps_weights_num_tensors(void);
 int sps_weights_tensor_info(int idx, char *name, int name_cap, int64_t *offset, int64_t *numel);
 int64_t sps_weights_numel(void);
 /* Copies the blob to the device and derives the folded BatchNorm scale/shift
- * (eval mode, eps = 1e-5).  Synchronises. */
+ * (eval mode, eps = 1e-5).  Blocking copies into fresh allocations (= sps_weights_create + sps_ctx_set_weights). */
 int sps_weights_load(sps_ctx *ctx, const float *blob_host, int64_t numel);
+/* A device-resident weight set that several contexts of one device share (a pipelined loop runs one context per
+ * stream: the module's .cuda() happens once, reference scripts/predict.py:59, not once per stream).
+ * sps_weights_create uploads (blocking copies, no device-wide synchronise); sps_ctx_set_weights attaches it to a
+ * context in O(1) without any synchronisation -- forwards issued afterwards use it, forwards already issued keep
+ * reading the previous set, which stays alive until its last user lets go; sps_weights_destroy drops the caller's
+ * reference.  out_channels as in sps_weights_load_head below. */
+typedef struct sps_weights_handle sps_weights_handle;
+int sps_weights_create(int device, const float *blob_host, int64_t numel, int out_channels, sps_weights_handle **out);
+int sps_weights_destroy(sps_weights_handle *w);
+int sps_ctx_set_weights(sps_ctx *ctx, sps_weights_handle *w);
 
 /* ---- forward ------------------------------------------------------------------------
  * Replaces SPSModel.forward (reference src/sps/models/models.py:20-30): quantise by
@@ -150,6 +160,35 @@ int sps_submap_voxel(sps_ctx *ctx, const float *scan_xyz_dev, int64_t ld, int64_
                      int64_t *n_sub, int64_t *n_scan_vox, void *stream);
 int sps_submap_voxel_ijk(sps_ctx *ctx, const int32_t *scan_ijk_dev, int64_t ld, int64_t n, float ds,
                          float *out_xyz_dev, int64_t *n_sub, int64_t *n_scan_vox, void *stream);
+
+/* ---- streaming filter (online path, stream-ordered end to end) --------------------------------
+ * The per-scan body of the reference's ROS node (c_ws/src/sps_filter/scripts/sps_node.py:88-176) without the
+ * transport, as four stream-ordered calls that never synchronise with the host: the row counts they produce stay in
+ * a caller-owned device array counts_dev (int32[4]) that the caller reads back ONCE, after the whole scan was issued.
+ *
+ * sps_transform_points: util.transform_point_cloud (reference util.py:187-194; sps_node.py:103, blt_dataset.py:69-70):
+ *   p' = T [p;1] with perspective divide in float64 (fused multiply-add chain over k = 0..3, the order numpy's dgemm
+ *   uses: bit-identical to the reference in float64), stored as float32 (out_f64 = 0; sps_node.py:107) or float64.
+ *   xyz_dev rows are float32 (in_f64 = 0) or float64 (in_f64 = 1) with row stride ld; T_host is the row-major 4x4
+ *   matrix ON THE HOST (passed by value to the kernel: no copy), NULL = identity.
+ * sps_filter_prepare: sps_node.py:103-117 + the tensor assembly of util.infer (util.py:163-176).  Writes into
+ *   batch_dev (float32 [2n, 5], caller-owned) the rows (0, x', y', z', 1) of the transformed scan followed by the rows
+ *   (0, vx, vy, vz, 0) of the variant-B submap (voxel corners of scan voxels INTERSECT map voxels, scan
+ *   first-occurrence order, as sps_submap_voxel), and counts_dev[0] = n_sub, [1] = n_scan_vox, [2] = n + n_sub.
+ *   Needs sps_map_upload (float form).
+ * sps_forward_n: sps_forward whose row count is read from DEVICE memory (*n_dev <= n_max; grids are sized for
+ *   n_max); scores_dev [n_max], rows >= *n_dev are left untouched.
+ * sps_compact_stable: the epsilon filter `scan[scores <= eps]` (sps_node.py:147-148): copies, in input order, the
+ *   first `cols` floats of every row i < n of rows_dev (row stride ld) whose score is <= eps to out_dev [., cols];
+ *   *count_dev = rows kept (NaN scores are dropped). */
+int sps_transform_points(sps_ctx *ctx, const void *xyz_dev, int in_f64, int64_t ld, int64_t n, const double *T_host,
+                         void *out_dev, int out_f64, int64_t ldo, void *stream);
+int sps_filter_prepare(sps_ctx *ctx, const void *raw_xyz_dev, int in_f64, int64_t ld, int64_t n, const double *T_host,
+                       float *batch_dev, int32_t *counts_dev, void *stream);
+int sps_forward_n(sps_ctx *ctx, const float *coords_dev, int64_t ld, int64_t n_max, const int32_t *n_dev, float voxel_size,
+                  float *scores_dev, void *stream);
+int sps_compact_stable(sps_ctx *ctx, const float *scores_dev, const float *rows_dev, int64_t ld, int cols, int64_t n,
+                       float eps, float *out_dev, int32_t *count_dev, void *stream);
 
 /* ---- variant-A submap (offline path) ----------------------------------------------------
  * Replaces BacchusDataset.select_closest_points (reference src/sps/datasets/blt_dataset.py:258-271:

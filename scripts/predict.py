@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Offline evaluation on the MI355X path -- the reference's ``scripts/predict.py`` (same options
 -w/--weights, -seq/--sequence, -c/--config; same six printed lines), with the Lightning Trainer loop
-(predict.py:64-67) replaced by a plain per-scan loop over SPSNet.predict_step.
+(predict.py:64-67) replaced by the stream-pipelined sps_amd.engine.ScanEngine (the loop bench.py measures): per
+scan one host->device copy + one fused forward+metrics call, ONE host synchronisation per sequence.
 
 Differences, on purpose:
   * ``--sequence`` is taken as ONE sequence id (the reference wraps the string in list(), which splits
@@ -25,16 +26,29 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import sps.datasets.blt_dataset as datasets  # noqa: E402
 import sps.models.models as models  # noqa: E402
 from sps_amd import parallel, synthetic  # noqa: E402
+from sps_amd.engine import ScanEngine  # noqa: E402
 
 DEFAULT_CONFIG_PATH = "./config/config.yaml"
 
 
 def synthetic_scans(n, voxel_size):
-    map_points = synthetic.build_map()
-    for i in range(n):
-        sc = synthetic.make_scene(scan_seed=100 + i, x_offset=0.5 * i - 2.0, voxel_size=voxel_size,
-                                  map_points=map_points)
-        yield torch.from_numpy(sc["batch"])
+    """BASELINE config 3's sequence: consecutive scans, the sensor advancing 0.5 m per scan; pinned host tensors, as the
+    reference's DataLoader (pin_memory=True, blt_dataset.py:102-118) would deliver them."""
+    for b in synthetic.make_sequence(n, voxel_size=voxel_size):
+        t = torch.from_numpy(b)
+        yield t.pin_memory() if torch.cuda.is_available() else t
+
+
+def batched(loader, k):
+    """k consecutive single-scan batches -> one [sum N, 6] tensor with batch column 0..k-1 (collate_fn layout)."""
+    group = []
+    for b in loader:
+        group.append(b)
+        if len(group) == k:
+            yield group
+            group = []
+    if group:
+        yield group
 
 
 @click.command()
@@ -43,13 +57,18 @@ def synthetic_scans(n, voxel_size):
               help="Run inference on a specific sequence. Otherwise, test split from config is used.")
 @click.option("--config", "-c", type=str, default=DEFAULT_CONFIG_PATH, help="Path to the config file (.yaml)")
 @click.option("--synthetic", "n_synth", type=int, default=0, help="evaluate N synthetic scans instead of $DATA")
-def main(weights, sequence, config, n_synth):
+@click.option("--batch-size", "-b", "batch_size", type=int, default=1,
+              help="scans per forward (batch column 0..b-1, BacchusModule.collate_fn layout); metrics stay per scan")
+@click.option("--streams", type=int, default=None, help="forwards in flight (HIP streams); default: the engine's")
+@click.option("--timing", is_flag=True, help="print scans/s of the evaluation loop (rank 0)")
+def main(weights, sequence, config, n_synth, batch_size, streams, timing):
     cfg = yaml.safe_load(open(config))
     if sequence:
         cfg["DATA"]["SPLIT"]["TEST"] = [sequence]
     print('Test seq: ', cfg["DATA"]["SPLIT"]["TEST"])
     assert len(cfg["DATA"]["SPLIT"]["TEST"]) == 1, "Only one test SEQ is allowed at a time!"
     cfg["TRAIN"]["BATCH_SIZE"] = 1
+    assert 1 <= batch_size <= 31, "batch size must be in [1, 31]"
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -60,14 +79,14 @@ def main(weights, sequence, config, n_synth):
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     if n_synth:
-        scans = list(synthetic_scans(n_synth, cfg["MODEL"]["VOXEL_SIZE"]))
-        loader = scans
+        loader = list(synthetic_scans(n_synth, cfg["MODEL"]["VOXEL_SIZE"]))
     else:
         data = datasets.BacchusModule(cfg, test=True)
         data.setup()
         loader = data.test_dataloader()
+    n_scans = len(loader)
 
-    model = models.SPSNet(cfg, len(loader))
+    model = models.SPSNet(cfg, n_scans)
     if weights:
         ckpt = torch.load(weights, map_location="cpu", weights_only=False)
         model.load_state_dict(ckpt["state_dict"])
@@ -75,22 +94,42 @@ def main(weights, sequence, config, n_synth):
         print("no --weights given: random-init weights (resnet.py:87-94 scheme)")
     model = model.to(dev).eval().freeze()
 
-    # per-scan rows [scan_idx, Loss, R2, dIoU, Precision, Recall, F1, 0, 0] of this rank's shard
-    rows = []
+    # The reference's loop (predict.py:64-67: trainer.predict -> predict_step per scan, three host syncs each) as a
+    # stream-ordered pipeline: group g of `batch_size` scans -> rank g mod W; every group is copied to the device and
+    # evaluated on one of the engine's streams; the 8 metric sums of every scan land in a device table; ONE
+    # synchronisation at the end of the sequence.
+    kw = {} if streams is None else {"streams": streams}
+    eng = ScanEngine(model, dev, table_rows=n_scans + batch_size, **kw)
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    idx = []                                              # scan index of every used table row
     with torch.no_grad():
-        for i, batch in enumerate(loader):
-            if i % world != rank:                      # scan i -> rank i mod W (parallel.shard_indices)
+        for g, group in enumerate(batched(loader, batch_size)):
+            if g % world != rank:                         # parallel.shard_indices over groups
                 continue
-            m = model.predict_step(batch.to(dev, non_blocking=True), i)
-            rows.append([float(i), m["loss"], m["r2"], m["dIoU"], m["precision"], m["recall"], m["f1"], 0.0, 0.0])
-    local_rows = torch.tensor(rows, dtype=torch.float64, device=dev).reshape(-1, parallel.ROW)
+            batch = group[0] if len(group) == 1 else datasets.BacchusModule.collate_fn([b[:, 1:] for b in group])
+            eng.submit(batch, len(group))
+            idx += [g * batch_size + j for j in range(len(group))]
+    sums = eng.finish()
+    n_local = len(idx)
+    local_rows = torch.empty((n_local, parallel.ROW), dtype=torch.float64, device=dev)
+    local_rows[:, 0] = torch.tensor(idx, dtype=torch.float64, device=dev)
+    local_rows[:, 1:] = sums[:n_local]
     gathered = parallel.gather_metric_rows(local_rows, world)      # one RCCL all-gather per sequence
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
     if rank == 0:
+        mean = parallel.mean_metrics(gathered)                     # mean of per-scan values (predict.py:80-83)
+        for m in (models.metrics_from_sums(r[1:].tolist()) for r in gathered.cpu()):
+            model.predict_loss.append(m["loss"]); model.predict_r2.append(m["r2"]); model.dIoU.append(m["dIoU"])
+            model.precision.append(m["precision"]); model.recall.append(m["recall"]); model.F1.append(m["f1"])
         print('\n########## Inference Metrics ##########')
-        for j, name in enumerate(["Loss", "R2", "dIoU", "Precision", "Recall", "F1"]):
-            col = gathered[:, 1 + j].cpu().numpy()
-            mean_value = float(np.sum(col) / max(len(col), 1))     # mean of per-scan values (predict.py:80-83)
-            print(f'{name} {"." * (12 - len(name))} {mean_value:.3f}')
+        for name in ["Loss", "R2", "dIoU", "Precision", "Recall", "F1"]:
+            print(f'{name} {"." * (12 - len(name))} {mean[name]:.3f}')
+        if timing:
+            print(f"timing: {len(gathered)} scans in {dt:.3f} s = {len(gathered) / dt:.1f} scans/s "
+                  f"({world} GPU(s), {len(eng.streams)} streams, batch {batch_size}, host->device copies included)")
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -21,6 +21,10 @@ def hipcc_path() -> str:
     return p
 
 
+def have_hipcc() -> bool:
+    return bool(shutil.which("hipcc")) or os.path.exists("/opt/rocm/bin/hipcc")
+
+
 def is_stale() -> bool:
     if not os.path.exists(LIB):
         return True

@@ -20,11 +20,21 @@ class SpsError(RuntimeError):
         self.code = code
 
 
+ABI_VERSION = 200          # sps_version() of the library this binding was written against
+
+
 def _load() -> C.CDLL:
-    path = _build.LIB
-    if not os.path.exists(path):
-        # building needs only hipcc (cross-compiles without a GPU); never falls back to CPU code
-        path = _build.build()
+    # SPS_LIB: diagnostic builds (tools/ablate*.sh, tune_conv.sh ...) live at their own path and never overwrite
+    # the product library
+    path = os.environ.get("SPS_LIB") or _build.LIB
+    if path == _build.LIB and (not os.path.exists(path) or _build.is_stale()):
+        # an edited .hip / .inc.h must never run against an old binary: rebuild when hipcc is here (it cross-compiles
+        # without a GPU); a box without hipcc runs the shipped .so, whose ABI version is checked below.
+        # Never falls back to CPU code.
+        if _build.have_hipcc():
+            path = _build.build()
+        elif not os.path.exists(path):
+            raise ImportError("libsps_hip.so is missing and hipcc is not available to build it")
     lib = C.CDLL(path)
     vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
     sig = {
@@ -37,6 +47,9 @@ def _load() -> C.CDLL:
         "sps_weights_tensor_info": (i32, [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
         "sps_weights_numel": (i64, []),
         "sps_weights_load": (i32, [vp, vp, i64]),
+        "sps_weights_create": (i32, [i32, vp, i64, i32, C.POINTER(vp)]),
+        "sps_weights_destroy": (i32, [vp]),
+        "sps_ctx_set_weights": (i32, [vp, vp]),
         "sps_forward": (i32, [vp, vp, i64, i64, f32, vp, vp]),
         "sps_forward_metrics": (i32, [vp, vp, i64, i64, f32, f32, i32, vp, vp, vp]),
         "sps_head_num_tensors": (i32, [i32]),
@@ -54,6 +67,10 @@ def _load() -> C.CDLL:
         "sps_map_upload_voxels": (i32, [vp, vp, i64, i64, vp]),
         "sps_submap_voxel": (i32, [vp, vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp]),
         "sps_submap_voxel_ijk": (i32, [vp, vp, i64, i64, f32, vp, C.POINTER(i64), C.POINTER(i64), vp]),
+        "sps_transform_points": (i32, [vp, vp, i32, i64, i64, vp, vp, i32, i64, vp]),
+        "sps_filter_prepare": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp]),
+        "sps_forward_n": (i32, [vp, vp, i64, i64, vp, f32, vp, vp]),
+        "sps_compact_stable": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),
         "sps_radius_grid_upload": (i32, [vp, vp, vp, vp, vp, i64, i64, C.c_double, C.c_double, vp]),
         "sps_radius_count": (i32, [vp, vp, i64, i64, vp, vp]),
         "sps_radius_fill": (i32, [vp, vp, i64, i64, vp, vp, vp]),
@@ -71,16 +88,21 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch: fail loudly
         fn.restype = res
         fn.argtypes = args
+    if lib.sps_version() != ABI_VERSION:
+        raise ImportError(f"{path} reports ABI version {lib.sps_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                          "(python -m sps_amd._build)")
     return lib
 
 
 lib = _load()
 EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
+           "sps_weights_create", "sps_weights_destroy", "sps_ctx_set_weights",
            "sps_forward", "sps_forward_metrics", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
            "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
-           "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_radius_grid_upload", "sps_radius_count",
+           "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_transform_points", "sps_filter_prepare", "sps_forward_n",
+           "sps_compact_stable", "sps_radius_grid_upload", "sps_radius_count",
            "sps_radius_fill", "sps_level_counts", "sps_get_voxels",
            "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_logits", "sps_get_feature"]
 
@@ -104,14 +126,37 @@ def weight_layout(out_channels: int = 1):
     return out
 
 
+class Weights:
+    """One device-resident weight set (sps_weights_create): uploaded once per device and parameter version, attached
+    to any number of contexts of that device in O(1)."""
+
+    def __init__(self, device: int, blob_host_ptr: int, numel: int, out_channels: int = 1):
+        h = C.c_void_p()
+        check(lib.sps_weights_create(int(device), blob_host_ptr, int(numel), int(out_channels), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib.sps_weights_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Context:
-    """Owns one ``sps_ctx`` (one per process and device)."""
+    """Owns one ``sps_ctx`` (one per process, device and stream)."""
 
     def __init__(self, device: int = 0):
         h = C.c_void_p()
         check(lib.sps_ctx_create(device, C.byref(h)))
         self.handle = h
         self.device = device
+        self.weights = None
 
     def close(self):
         if getattr(self, "handle", None):
@@ -130,6 +175,11 @@ class Context:
 
     def load_weights(self, blob_host_ptr: int, numel: int, out_channels: int = 1):
         check(lib.sps_weights_load_head(self.handle, blob_host_ptr, int(numel), int(out_channels)))
+        self.weights = None
+
+    def set_weights(self, weights: "Weights"):
+        check(lib.sps_ctx_set_weights(self.handle, weights.handle))
+        self.weights = weights          # keeps the Python owner alive as long as the context uses it
 
     def forward_head(self, coords_ptr: int, ld: int, n: int, voxel_size: float, feats_ptr, t_base: float,
                      out_ptr: int, ldo: int, activation: int, stream: int):
@@ -183,6 +233,30 @@ class Context:
         a, b = C.c_int64(), C.c_int64()
         check(lib.sps_submap_voxel_ijk(self.handle, scan_ptr, ld, n, ds, out_ptr, C.byref(a), C.byref(b), stream))
         return a.value, b.value
+
+    @staticmethod
+    def _mat(T):
+        """4x4 host matrix -> ctypes double[16] (row-major), None = identity."""
+        if T is None:
+            return None
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(T, dtype=np.float64).reshape(16))
+        return (C.c_double * 16)(*a.tolist())
+
+    def transform_points(self, xyz_ptr: int, in_f64: bool, ld: int, n: int, T, out_ptr: int, out_f64: bool, ldo: int,
+                         stream: int):
+        check(lib.sps_transform_points(self.handle, xyz_ptr, int(in_f64), ld, n, self._mat(T), out_ptr, int(out_f64), ldo,
+                                       stream))
+
+    def filter_prepare(self, raw_ptr: int, in_f64: bool, ld: int, n: int, T, batch_ptr: int, counts_ptr: int, stream: int):
+        check(lib.sps_filter_prepare(self.handle, raw_ptr, int(in_f64), ld, n, self._mat(T), batch_ptr, counts_ptr, stream))
+
+    def forward_n(self, coords_ptr: int, ld: int, n_max: int, n_dev_ptr: int, voxel_size: float, scores_ptr: int, stream: int):
+        check(lib.sps_forward_n(self.handle, coords_ptr, ld, n_max, n_dev_ptr, voxel_size, scores_ptr, stream))
+
+    def compact_stable(self, scores_ptr: int, rows_ptr: int, ld: int, cols: int, n: int, eps: float, out_ptr: int,
+                       count_ptr: int, stream: int):
+        check(lib.sps_compact_stable(self.handle, scores_ptr, rows_ptr, ld, cols, n, eps, out_ptr, count_ptr, stream))
 
     def level_counts(self):
         out = (C.c_int64 * NUM_LEVELS)()

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_metrics(float *__restrict__ scores, int
 // predict_step (models.py:84-105) for the scores they produce, grid-striding over the points.
 __global__ __launch_bounds__(256) void k_tail(const float *__restrict__ logits, const int *__restrict__ inv, int n,
                                                float *__restrict__ scores, int gs, PyramidArgs pa, int gb, MetricsArgs m) {
+  if (pa.n_dev) n = min(n, *pa.n_dev);
   if ((int)blockIdx.x >= gs) {  // hash slots used by this forward go back to "free"
     const int b = (int)blockIdx.x - gs;
     bhash_cleanup(pa, b / gb, b % gb, gb);
@@ -204,10 +205,15 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_keep_count(const int *__restrict
   if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
 }
 
+// ROWS5 = false: out rows are [x, y, z] with stride ldo (util.prune's return value).
+// ROWS5 = true : out rows are (b = 0, x, y, z, t = 0) with stride ldo, written BEHIND the n_scan scan rows of an
+//                inference batch (util.infer's tensor, util.py:163-176); counts3 = [n_sub, (n_scan_vox), n_scan + n_sub].
+template <bool ROWS5>
 __global__ __launch_bounds__(SCAN_BLOCK) void k_keep_write(const int *__restrict__ keep,
                                                             const uint64_t *__restrict__ srckey, int n, float ds,
                                                             const int *__restrict__ block_sums,
-                                                            float *__restrict__ out_xyz, int *__restrict__ count_out) {
+                                                            float *__restrict__ out_xyz, int64_t ldo,
+                                                            int *__restrict__ count_out) {
   __shared__ int lds[SCAN_BLOCK / 64];
   __shared__ int wave_off[SCAN_BLOCK / 64];
   int part = 0;
@@ -229,11 +235,105 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_keep_write(const int *__restrict
   if (flag) {
     int b, x, y, z, t;
     key_unpack(srckey[p], b, x, y, z, t);
-    float *o = out_xyz + (size_t)(base + off + in_wave) * 3;
+    float *o = out_xyz + (size_t)(base + off + in_wave) * ldo;
+    if (ROWS5) {
+      o[0] = 0.f;  // batch index (util.py:170)
+      o[4] = 0.f;  // MAP_TIMESTAMP (util.py:21)
+      ++o;
+    }
     // torch: int32 tensor * python float -> float32 (util.py:112)
     o[0] = (float)x * ds;
     o[1] = (float)y * ds;
     o[2] = (float)z * ds;
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    count_out[0] = base + tot;
+    if (ROWS5) count_out[2] = n + base + tot;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming filter (c_ws/src/sps_filter/scripts/sps_node.py:88-176 without the ROS transport)
+// ------------------------------------------------------------------------------------------
+struct Mat4 {
+  double m[16];  // row-major 4x4
+};
+
+// util.transform_point_cloud (util.py:187-194): t = [p;1] @ T^T in float64, then t[:3] / t[3].  numpy evaluates the
+// product with dgemm, whose inner loop is a chain of fused multiply-adds over k = 0..3 starting from a rounded product;
+// the same chain here reproduces tests/golden/transform.npz bit for bit in float64.  The result is stored as float32
+// (sps_node.py:107: torch.tensor(..., dtype=float32)) or float64.  WITH_BT also writes the batch index 0 and the scan
+// time stamp 1 around x, y, z: rows (b, x, y, z, t) of util.infer's tensor (util.py:170-172).
+template <typename TIN, typename TOUT, bool WITH_BT>
+__global__ void k_transform_points(const TIN *__restrict__ in, int64_t ld, int n, Mat4 T, int identity,
+                                   TOUT *__restrict__ out, int64_t ldo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const TIN *r = in + (size_t)p * ld;
+  const double x = (double)r[0], y = (double)r[1], z = (double)r[2];
+  double o[3] = {x, y, z};
+  if (!identity) {
+    double t[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      double acc = __dmul_rn(x, T.m[4 * j]);
+      acc = __fma_rn(y, T.m[4 * j + 1], acc);
+      acc = __fma_rn(z, T.m[4 * j + 2], acc);
+      acc = __fma_rn(1.0, T.m[4 * j + 3], acc);
+      t[j] = acc;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = __ddiv_rn(t[j], t[3]);
+  }
+  TOUT *w = out + (size_t)p * ldo;
+  if (WITH_BT) {
+    w[0] = (TOUT)0;
+    w[4] = (TOUT)1;  // SCAN_TIMESTAMP (util.py:20)
+    ++w;
+  }
+  w[0] = (TOUT)o[0];
+  w[1] = (TOUT)o[1];
+  w[2] = (TOUT)o[2];
+}
+
+// epsilon filter (sps_node.py:147-148: `scan[scores <= eps]`): order-preserving compaction of the rows whose
+// score is <= eps (NaN scores -- unrepresentable coordinates -- are dropped).  Two passes over SCAN_BLOCK-row chunks:
+// count, then ballot / prefix-sum placement; no atomics, so the output order is the input order.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_stable_count(const float *__restrict__ scores, int n, float eps,
+                                                              int *__restrict__ block_sums) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int flag = p < n && scores[p] <= eps;
+  const int tot = block_reduce_sum(flag, lds);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_stable_write(const float *__restrict__ scores, int n, float eps,
+                                                              const int *__restrict__ block_sums,
+                                                              const float *__restrict__ rows, int64_t ld, int cols,
+                                                              float *__restrict__ out, int *__restrict__ count_out) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int wave_off[SCAN_BLOCK / 64];
+  int part = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) part += block_sums[i];
+  const int base = block_reduce_sum(part, lds);
+  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
+  const int flag = p < n && scores[p] <= eps;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned long long bal = __ballot(flag);
+  const int in_wave = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_off[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0, tot = 0;
+  for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+    const int c = wave_off[i];
+    if (i < wave) off += c;
+    tot += c;
+  }
+  if (flag) {
+    const float *r = rows + (size_t)p * ld;
+    float *o = out + (size_t)(base + off + in_wave) * cols;
+    for (int j = 0; j < cols; ++j) o[j] = r[j];
   }
   if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *count_out = base + tot;
 }

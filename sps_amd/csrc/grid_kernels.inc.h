@@ -98,7 +98,9 @@ __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restric
                                                            float t_base, BHash h, int *__restrict__ sslot,
                                                            unsigned char *__restrict__ sbit, int *err,
                                                            uint4 *__restrict__ zero_region, int zero_vec4,
-                                                           double *__restrict__ metrics_zero, int metrics_n) {
+                                                           double *__restrict__ metrics_zero, int metrics_n,
+                                                           const int *__restrict__ n_dev) {
+  if (n_dev) n = min(n, *n_dev);  // row count produced on the device by an earlier kernel of the stream (sps_forward_n)
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p < metrics_n) metrics_zero[p] = 0.0;  // sps_forward_metrics: the sums its tail kernel will accumulate into
   // first kernel of the forward: clears the counters and every tile mask of the previous forward (they stay
@@ -151,6 +153,7 @@ struct PyramidArgs {
   int *counts;        // [0..4] voxels per level, [8..12] blocks per level
   int *block_sums;    // scan scratch, `sums_stride` ints per level
   int sums_stride;
+  const int *n_dev;   // null, or the device-side point count (<= the host-side bound the grids were sized for)
 };
 
 // levels 1..4 in one pass: one thread per LEVEL-0 block inserts its ancestor block at every coarser
@@ -240,7 +243,7 @@ __device__ inline int2 block_exclusive_scan2(int v0, int v1, const int *__restri
 __global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(PyramidArgs a, int lv0, int n0) {
   __shared__ int lds[SCAN_BLOCK / 64];
   const int l = lv0 + blockIdx.y;
-  const int n = l == 0 ? n0 : a.counts[8];
+  const int n = l == 0 ? (a.n_dev ? min(n0, *a.n_dev) : n0) : a.counts[8];
   if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
   const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
   int flag = 0, cnt = 0;
@@ -264,7 +267,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv
   __shared__ int lds[SCAN_BLOCK / 64];
   __shared__ int2 wave_off[SCAN_BLOCK / 64];
   const int l = lv0 + blockIdx.y;
-  const int n = l == 0 ? n0 : a.counts[8];
+  const int n = l == 0 ? (a.n_dev ? min(n0, *a.n_dev) : n0) : a.counts[8];
   const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   if ((int)blockIdx.x >= nwg) return;  // counts were zeroed by the reset
   const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
@@ -310,6 +313,7 @@ __global__ __launch_bounds__(256) void k_rows_ancestors(const int *__restrict__ 
     return;
   }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.n_dev) n = min(n, *a.n_dev);
   if (p >= n) return;
   const int s = sslot[p];
   int row = -1;

@@ -32,8 +32,10 @@
 #include <cstdint>
 #include <cstdio>
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -145,6 +147,27 @@ struct Feat {
 
 }  // namespace
 
+// Device-resident weights of one network: immutable once uploaded, shared by every context of the device that
+// runs the same parameters (23 pipelined contexts read ONE copy; attaching it to a context is O(1), no sync).
+struct sps_weights {
+  int device = 0;
+  float *blob = nullptr;  // reference state_dict order
+  float *ss = nullptr;    // folded BN scale / shift
+  float *wu = nullptr;    // unit-major permuted conv kernels (k_conv B operand)
+  float final_bias = 0.f;
+  const NetSpec *net = nullptr;
+  ~sps_weights() {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();  // forwards in flight may still read them
+    (void)hipFree(blob);
+    (void)hipFree(ss);
+    (void)hipFree(wu);
+  }
+};
+struct sps_weights_handle {  // what the C ABI hands out: one reference
+  std::shared_ptr<sps_weights> w;
+};
+
 struct sps_ctx {
   int device = 0;
   int64_t cap = 0;       // arena capacity in rows (points)
@@ -163,6 +186,7 @@ struct sps_ctx {
   int *keep = nullptr;
   double *macc = nullptr;    // metrics accumulators [32*8]
   unsigned long long *pairs = nullptr;  // [128]
+  std::shared_ptr<sps_weights> weights;  // the attached weight set; the three pointers below are views into it
   float *blob = nullptr;     // weights
   float *ss = nullptr;       // folded scale/shift
   float *wu = nullptr;       // unit-major permuted conv kernels (k_conv B operand)
@@ -330,6 +354,14 @@ int reserve(sps_ctx *c, int64_t n) {
   c->hcap = hcap;
   c->last_n = 0;
   HIP_TRY(hipMemset(c->zero_region, 0, (16 + (size_t)(cap / 16) * 4 * 10) * sizeof(uint32_t)));  // counters + every mask word once
+  // the block hashes start clean here (allocation time), not in the first forward: every later forward cleans up
+  // after itself, so a context that was reserved up front issues no fill in its steady state
+  HIP_TRY(hipMemset(c->hash_keys_all, 0xFF, (size_t)hcap * SPS_NUM_LEVELS * sizeof(uint64_t)));
+  HIP_TRY(hipMemset(c->hash_mask_all, 0, (size_t)hcap * SPS_NUM_LEVELS * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c->hash_first_all, 0x7F, (size_t)hcap * SPS_NUM_LEVELS * sizeof(int)));
+  HIP_TRY(hipMemset(c->hash_occ_all, 0, (size_t)(hcap / 32) * SPS_NUM_LEVELS * sizeof(uint32_t)));
+  HIP_TRY(hipDeviceSynchronize());
+  c->tables_dirty = false;
   return SPS_OK;
 }
 
@@ -359,6 +391,7 @@ PyramidArgs pyramid_args(sps_ctx *c) {
   a.counts = c->counts;
   a.block_sums = c->block_sums;
   a.sums_stride = (int)(2 * (c->cap / SCAN_BLOCK + 8));
+  a.n_dev = nullptr;
   return a;
 }
 
@@ -398,13 +431,23 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   // chain of dependent load -> MFMA rounds: one column tile per wave and four splits per tile (one workgroup, LDS
   // reduction) shorten the chain; serial 0.552 -> 0.506 ms, pipelined throughput unchanged
   Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{1, 4};
-  // tuning hook (diagnostics): SPS_GEOM_L<level>="<full>,<S>"  full=1 -> one wave owns all column tiles
-  char name[32];
-  snprintf(name, sizeof name, "SPS_GEOM_L%d", level);
-  if (const char *e = getenv(name)) {
+  // tuning hook (diagnostics): SPS_GEOM_L<level>="<full>,<S>"  full=1 -> one wave owns all column tiles; read once
+  struct Hook {
+    bool set = false;
     int full = 0, S = 1;
-    if (sscanf(e, "%d,%d", &full, &S) == 2 && (S == 1 || S == 2 || S == 4)) g = {full ? nt : 1, S};
-  }
+  };
+  static const std::array<Hook, SPS_NUM_LEVELS> hooks = [] {
+    std::array<Hook, SPS_NUM_LEVELS> h{};
+    for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+      char name[32];
+      snprintf(name, sizeof name, "SPS_GEOM_L%d", l);
+      const char *e = getenv(name);
+      int full = 0, S = 1;
+      if (e && sscanf(e, "%d,%d", &full, &S) == 2 && (S == 1 || S == 2 || S == 4)) h[l] = Hook{true, full, S};
+    }
+    return h;
+  }();
+  if (level >= 0 && level < SPS_NUM_LEVELS && hooks[level].set) g = {hooks[level].full ? nt : 1, hooks[level].S};
   return g;
 }
 
@@ -577,6 +620,19 @@ std::vector<Feat> feature_taps(sps_ctx *c) {
   };
 }
 
+template <typename TIN>
+int transform_launch(const TIN *in, int64_t ld, int64_t n, const Mat4 &T, int identity, void *out, int out_f64,
+                            bool with_bt, int64_t ldo, hipStream_t st) {
+  const dim3 g((unsigned)((n + 255) / 256)), b(256);
+  if (with_bt)
+    hipLaunchKernelGGL((k_transform_points<TIN, float, true>), g, b, 0, st, in, ld, (int)n, T, identity, (float *)out, ldo);
+  else if (out_f64)
+    hipLaunchKernelGGL((k_transform_points<TIN, double, false>), g, b, 0, st, in, ld, (int)n, T, identity, (double *)out, ldo);
+  else
+    hipLaunchKernelGGL((k_transform_points<TIN, float, false>), g, b, 0, st, in, ld, (int)n, T, identity, (float *)out, ldo);
+  return SPS_OK;
+}
+
 }  // namespace
 
 // ============================================================================================
@@ -585,7 +641,7 @@ std::vector<Feat> feature_taps(sps_ctx *c) {
 extern "C" {
 
 const char *sps_last_error(void) { return g_err.c_str(); }
-int sps_version(void) { return 100; }
+int sps_version(void) { return 200; }
 
 int sps_ctx_create(int device, sps_ctx **out) {
   if (!out) return fail(SPS_ERR_INVALID, "out is null");
@@ -595,14 +651,10 @@ int sps_ctx_create(int device, sps_ctx **out) {
   HIP_TRY(hipSetDevice(device));
   sps_ctx *c = new sps_ctx();
   c->device = device;
-  const NetSpec &s = spec(MAX_HEAD);  // the widest head: every spec(k) fits
   c->net = &spec(1);
   HIP_TRY(hipMalloc((void **)&c->err, sizeof(int)));
   HIP_TRY(hipMalloc((void **)&c->macc, 32 * 8 * sizeof(double)));
   HIP_TRY(hipMalloc((void **)&c->pairs, 128 * sizeof(unsigned long long)));
-  HIP_TRY(hipMalloc((void **)&c->blob, s.numel * sizeof(float)));
-  HIP_TRY(hipMalloc((void **)&c->ss, s.ss_numel * sizeof(float)));
-  HIP_TRY(hipMalloc((void **)&c->wu, s.wu_numel * sizeof(float)));
   HIP_TRY(hipMemset(c->err, 0, sizeof(int)));
   *out = c;
   return SPS_OK;
@@ -616,9 +668,7 @@ int sps_ctx_destroy(sps_ctx *c) {
   (void)hipFree(c->err);
   (void)hipFree(c->macc);
   (void)hipFree(c->pairs);
-  (void)hipFree(c->blob);
-  (void)hipFree(c->ss);
-  (void)hipFree(c->wu);
+  c->weights.reset();
   if (c->map_keys_alloc) (void)hipFree(c->map_keys_alloc);
   for (void *p : c->rg_allocs) (void)hipFree(p);
   delete c;
@@ -672,14 +722,16 @@ int64_t sps_head_numel(int out_channels) {
   return spec(out_channels).numel;
 }
 
-int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) { return sps_weights_load_head(c, blob, numel, 1); }
-
-int sps_weights_load_head(sps_ctx *c, const float *blob, int64_t numel, int out_channels) {
+int sps_weights_create(int device, const float *blob, int64_t numel, int out_channels, sps_weights_handle **out) {
+  if (!out) return fail(SPS_ERR_INVALID, "out is null");
   if (out_channels < 1 || out_channels > MAX_HEAD) return fail(SPS_ERR_INVALID, "out_channels must be in [1,%d]", MAX_HEAD);
   const NetSpec &s = spec(out_channels);
-  if (!c || !blob) return fail(SPS_ERR_INVALID, "null argument");
+  if (!blob) return fail(SPS_ERR_INVALID, "null argument");
   if (numel != s.numel) return fail(SPS_ERR_INVALID, "blob has %lld floats, expected %lld", (long long)numel, (long long)s.numel);
-  HIP_TRY(hipSetDevice(c->device));
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(SPS_ERR_INVALID, "device %d out of range (%d devices)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
   std::vector<float> ss((size_t)s.ss_numel);
   for (const ConvSpec &cs : s.convs) {
     float *sc = ss.data() + cs.ss_off, *sh = sc + cs.cout;
@@ -731,14 +783,52 @@ int sps_weights_load_head(sps_ctx *c, const float *blob, int64_t numel, int out_
       sc2[j] = 1.f;
     }
   }
-  c->final_bias = blob[s.bias_off];
-  c->net = &s;
-  HIP_TRY(hipDeviceSynchronize());  // forwards in flight on any stream still read the old weights
-  HIP_TRY(hipMemcpy(c->wu, wu.data(), wu.size() * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->blob, blob, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
+  auto w = std::make_shared<sps_weights>();
+  w->device = device;
+  w->final_bias = blob[s.bias_off];
+  w->net = &s;
+  // fresh allocations: nothing in flight reads them, so plain blocking copies and no device-wide synchronise
+  if (hipMalloc((void **)&w->blob, (size_t)numel * sizeof(float)) != hipSuccess ||
+      hipMalloc((void **)&w->ss, ss.size() * sizeof(float)) != hipSuccess ||
+      hipMalloc((void **)&w->wu, wu.size() * sizeof(float)) != hipSuccess)
+    return fail(SPS_ERR_NOMEM, "hipMalloc for the weights failed");
+  HIP_TRY(hipMemcpy(w->wu, wu.data(), wu.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(w->blob, blob, (size_t)numel * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(w->ss, ss.data(), ss.size() * sizeof(float), hipMemcpyHostToDevice));
+  *out = new sps_weights_handle{std::move(w)};
+  return SPS_OK;
+}
+
+int sps_weights_destroy(sps_weights_handle *h) {
+  delete h;  // the device memory goes when the last context that uses it lets go
+  return SPS_OK;
+}
+
+int sps_ctx_set_weights(sps_ctx *c, sps_weights_handle *h) {
+  if (!c || !h || !h->w) return fail(SPS_ERR_INVALID, "null argument");
+  if (h->w->device != c->device) return fail(SPS_ERR_INVALID, "weights live on device %d, the context on %d", h->w->device, c->device);
+  // forwards already issued keep the old set alive through the kernel arguments' owner: the context holds the
+  // previous shared_ptr until here, and an old set is only freed after a device synchronise (~sps_weights)
+  c->weights = h->w;
+  c->blob = h->w->blob;
+  c->ss = h->w->ss;
+  c->wu = h->w->wu;
+  c->final_bias = h->w->final_bias;
+  c->net = h->w->net;
   c->have_weights = true;
   return SPS_OK;
+}
+
+int sps_weights_load(sps_ctx *c, const float *blob, int64_t numel) { return sps_weights_load_head(c, blob, numel, 1); }
+
+int sps_weights_load_head(sps_ctx *c, const float *blob, int64_t numel, int out_channels) {
+  if (!c) return fail(SPS_ERR_INVALID, "null argument");
+  sps_weights_handle *h = nullptr;
+  int rc = sps_weights_create(c->device, blob, numel, out_channels, &h);
+  if (rc != SPS_OK) return rc;
+  rc = sps_ctx_set_weights(c, h);
+  delete h;  // the context holds the only reference
+  return rc;
 }
 
 // what the caller wants out of one forward: the SPS scores (head == false: `final` fused into
@@ -753,6 +843,8 @@ struct ForwardOpts {
   double *metrics_out = nullptr;
   float eps = 0.f;
   int n_batches = 0;
+  // sps_forward_n: the row count lives on the device (written by an earlier kernel of the stream); n is its bound
+  const int *n_dev = nullptr;
 };
 
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
@@ -762,6 +854,16 @@ int sps_forward(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs
   if (c && c->have_weights && c->net->out_channels != 1)
     return fail(SPS_ERR_INVALID, "the loaded weights have a %d-channel head: use sps_forward_head", c->net->out_channels);
   return forward_impl(c, coords, ld, n, vs, scores, ForwardOpts{}, stream);
+}
+
+int sps_forward_n(sps_ctx *c, const float *coords, int64_t ld, int64_t n_max, const int32_t *n_dev, float vs, float *scores,
+                  void *stream) {
+  if (c && c->have_weights && c->net->out_channels != 1)
+    return fail(SPS_ERR_INVALID, "the loaded weights have a %d-channel head: use sps_forward_head", c->net->out_channels);
+  if (!n_dev) return fail(SPS_ERR_INVALID, "n_dev is null");
+  ForwardOpts fo;
+  fo.n_dev = n_dev;
+  return forward_impl(c, coords, ld, n_max, vs, scores, fo, stream);
 }
 
 int sps_forward_head(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, const float *feats, float t_base,
@@ -822,7 +924,9 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   c->prof_n = 0;
   prof_mark(c, "begin", st);
   Level &L0 = c->lv[0];
-  const PyramidArgs pa = pyramid_args(c);
+  PyramidArgs pa = pyramid_args(c);
+  pa.n_dev = fo.n_dev;
+  if (fo.n_dev && (fo.head || fo.feats || fo.metrics_out)) return fail(SPS_ERR_INVALID, "a device-side row count is only supported by sps_forward_n");
   if (!skip_front) {
   // ---- reset: the block hashes are cleaned by the previous forward; full reset only when dirty
   if (c->tables_dirty) {
@@ -847,7 +951,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   // (the first kernel also clears the counters and tile masks of the previous forward)
   hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, fo.t_base, L0.h, L0.sslot, L0.sbit,
                      c->err, reinterpret_cast<uint4 *>(c->zero_region), (int)(c->zero_bytes / 16), fo.metrics_out,
-                     fo.metrics_out ? fo.n_batches * 8 : 0);
+                     fo.metrics_out ? fo.n_batches * 8 : 0, fo.n_dev);
   hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
   // ---- point rows + (levels 1..4) every coarser level straight from the level-0 blocks, one launch
@@ -1070,26 +1174,35 @@ static int map_upload_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, in
   return SPS_OK;
 }
 
-static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_t n, float ds, float *out_xyz,
-                       int64_t *n_sub, int64_t *n_scan_vox, void *stream) {
-  if (!c || !n_sub || !n_scan_vox) return fail(SPS_ERR_INVALID, "null argument");
+// rows5 = false: out rows [x,y,z] (stride ldo), counts to the host (synchronises) -- util.prune.
+// rows5 = true : out rows (0,x,y,z,0) appended behind the n scan rows of an inference batch, counts stay on the
+//                device (counts_dev[0] = n_sub, [1] = n_scan_vox, [2] = n + n_sub), no synchronisation.
+static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_t n, float ds, float *out_xyz, int64_t ldo,
+                       bool rows5, int32_t *counts_dev, int64_t *n_sub, int64_t *n_scan_vox, void *stream) {
+  if (!c || (!rows5 && (!n_sub || !n_scan_vox)) || (rows5 && !counts_dev)) return fail(SPS_ERR_INVALID, "null argument");
   if (!c->map.keys) return fail(SPS_ERR_INVALID, "sps_map_upload has not been called");
   if (n < 0 || ld < 3 || (n > 0 && (!src || !out_xyz))) return fail(SPS_ERR_INVALID, "bad arguments");
   if (!(ds > 0.f)) return fail(SPS_ERR_INVALID, "ds must be > 0");
   if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points (limit %d)", SPS_MAX_POINTS);
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
-  *n_sub = 0;
-  *n_scan_vox = 0;
-  if (n == 0) return SPS_OK;
+  if (!rows5) {
+    *n_sub = 0;
+    *n_scan_vox = 0;
+  }
+  if (n == 0) {
+    if (rows5) HIP_TRY(hipMemsetAsync(counts_dev, 0, 3 * sizeof(int32_t), st));
+    return SPS_OK;
+  }
   if (n > c->cap) {
     int rc = reserve(c, n);
     if (rc != SPS_OK) return rc;
   }
   SubmapScratch &L = c->sub;
+  int *cnt = rows5 ? counts_dev : c->counts + 5;  // [0] = n_sub, [1] = n_scan_vox
   HIP_TRY(hipMemsetAsync(L.h.keys, 0xFF, (size_t)c->hcap * sizeof(uint64_t), st));
   HIP_TRY(hipMemsetAsync(L.h.first, 0x7F, (size_t)c->hcap * sizeof(int), st));
-  HIP_TRY(hipMemsetAsync(c->counts + 5, 0, 2 * sizeof(int), st));
+  HIP_TRY(hipMemsetAsync(cnt, 0, 2 * sizeof(int), st));
   const unsigned g = (unsigned)((n + 255) / 256);
   if (ijk)
     hipLaunchKernelGGL(k_scan_trunc_insert<true>, dim3(g), dim3(256), 0, st, src, ld, (int)n, ds, L.h, L.srckey,
@@ -1098,16 +1211,77 @@ static int submap_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_
     hipLaunchKernelGGL(k_scan_trunc_insert<false>, dim3(g), dim3(256), 0, st, src, ld, (int)n, ds, L.h, L.srckey,
                        L.pslot, c->err);
   hipLaunchKernelGGL(k_submap_filter, dim3(g), dim3(256), 0, st, L.pslot, L.h.first, L.srckey, (int)n, c->map,
-                     c->keep, c->counts + 6);
+                     c->keep, cnt + 1);
   const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
   hipLaunchKernelGGL(k_keep_count, dim3(nb), dim3(SCAN_BLOCK), 0, st, c->keep, (int)n, c->block_sums);
-  hipLaunchKernelGGL(k_keep_write, dim3(nb), dim3(SCAN_BLOCK), 0, st, c->keep, L.srckey, (int)n, ds, c->block_sums,
-                     out_xyz, c->counts + 5);
+  if (rows5) {
+    hipLaunchKernelGGL(k_keep_write<true>, dim3(nb), dim3(SCAN_BLOCK), 0, st, c->keep, L.srckey, (int)n, ds, c->block_sums,
+                       out_xyz, ldo, cnt);
+    HIP_TRY(hipGetLastError());
+    return SPS_OK;
+  }
+  hipLaunchKernelGGL(k_keep_write<false>, dim3(nb), dim3(SCAN_BLOCK), 0, st, c->keep, L.srckey, (int)n, ds, c->block_sums,
+                     out_xyz, ldo, cnt);
   int res[2] = {0, 0};
-  HIP_TRY(hipMemcpyAsync(res, c->counts + 5, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipMemcpyAsync(res, cnt, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
   *n_sub = res[0];
   *n_scan_vox = res[1];
+  return SPS_OK;
+}
+
+static int transform_impl(sps_ctx *c, const void *xyz, int in_f64, int64_t ld, int64_t n, const double *T_host, void *out,
+                          int out_f64, bool with_bt, int64_t ldo, void *stream) {
+  if (!c || n < 0 || ld < 3 || ldo < (with_bt ? 5 : 3) || (n > 0 && (!xyz || !out))) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points (limit %d)", SPS_MAX_POINTS);
+  HIP_TRY(hipSetDevice(c->device));
+  if (n == 0) return SPS_OK;
+  Mat4 T{};
+  for (int i = 0; i < 16; ++i) T.m[i] = T_host ? T_host[i] : (i % 5 == 0 ? 1.0 : 0.0);
+  const int identity = T_host ? 0 : 1;
+  if (in_f64)
+    transform_launch((const double *)xyz, ld, n, T, identity, out, out_f64, with_bt, ldo, (hipStream_t)stream);
+  else
+    transform_launch((const float *)xyz, ld, n, T, identity, out, out_f64, with_bt, ldo, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_transform_points(sps_ctx *c, const void *xyz_dev, int in_f64, int64_t ld, int64_t n, const double *T_host,
+                         void *out_dev, int out_f64, int64_t ldo, void *stream) {
+  return transform_impl(c, xyz_dev, in_f64, ld, n, T_host, out_dev, out_f64, false, ldo, stream);
+}
+
+int sps_filter_prepare(sps_ctx *c, const void *raw_xyz_dev, int in_f64, int64_t ld, int64_t n, const double *T_host,
+                       float *batch_dev, int32_t *counts_dev, void *stream) {
+  if (c && !(c->map_ds > 0.f)) return fail(SPS_ERR_INVALID, "sps_map_upload (float form) has not been called");
+  int rc = transform_impl(c, raw_xyz_dev, in_f64, ld, n, T_host, batch_dev, 0, true, 5, stream);
+  if (rc != SPS_OK) return rc;
+  // scan rows are in place; the submap rows go behind them
+  return submap_impl(c, batch_dev + 1, false, 5, n, c->map_ds, batch_dev + (size_t)n * 5, 5, true, counts_dev, nullptr,
+                     nullptr, stream);
+}
+
+int sps_compact_stable(sps_ctx *c, const float *scores_dev, const float *rows_dev, int64_t ld, int cols, int64_t n, float eps,
+                       float *out_dev, int32_t *count_dev, void *stream) {
+  if (!c || !count_dev || n < 0 || cols < 1 || ld < cols || (n > 0 && (!scores_dev || !rows_dev || !out_dev)))
+    return fail(SPS_ERR_INVALID, "bad arguments");
+  if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points (limit %d)", SPS_MAX_POINTS);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (n == 0) {
+    HIP_TRY(hipMemsetAsync(count_dev, 0, sizeof(int32_t), st));
+    return SPS_OK;
+  }
+  if (n > c->cap) {
+    int rc = reserve(c, n);
+    if (rc != SPS_OK) return rc;
+  }
+  const int nb = (int)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+  hipLaunchKernelGGL(k_stable_count, dim3(nb), dim3(SCAN_BLOCK), 0, st, scores_dev, (int)n, eps, c->block_sums);
+  hipLaunchKernelGGL(k_stable_write, dim3(nb), dim3(SCAN_BLOCK), 0, st, scores_dev, (int)n, eps, c->block_sums, rows_dev, ld,
+                     cols, out_dev, count_dev);
+  HIP_TRY(hipGetLastError());
   return SPS_OK;
 }
 
@@ -1135,11 +1309,11 @@ int sps_map_upload_voxels(sps_ctx *c, const int32_t *ijk, int64_t ld, int64_t m,
 int sps_submap_voxel(sps_ctx *c, const float *scan_xyz, int64_t ld, int64_t n, float *out_xyz, int64_t *n_sub,
                      int64_t *n_scan_vox, void *stream) {
   if (c && !(c->map_ds > 0.f)) return fail(SPS_ERR_INVALID, "the map was uploaded as voxels: use sps_submap_voxel_ijk");
-  return submap_impl(c, scan_xyz, false, ld, n, c ? c->map_ds : 0.f, out_xyz, n_sub, n_scan_vox, stream);
+  return submap_impl(c, scan_xyz, false, ld, n, c ? c->map_ds : 0.f, out_xyz, 3, false, nullptr, n_sub, n_scan_vox, stream);
 }
 int sps_submap_voxel_ijk(sps_ctx *c, const int32_t *scan_ijk, int64_t ld, int64_t n, float ds, float *out_xyz,
                          int64_t *n_sub, int64_t *n_scan_vox, void *stream) {
-  return submap_impl(c, scan_ijk, true, ld, n, ds, out_xyz, n_sub, n_scan_vox, stream);
+  return submap_impl(c, scan_ijk, true, ld, n, ds, out_xyz, 3, false, nullptr, n_sub, n_scan_vox, stream);
 }
 
 int sps_radius_grid_upload(sps_ctx *c, const uint64_t *cell_keys_dev, const int32_t *cell_start_dev,
@@ -1241,6 +1415,7 @@ int sps_get_inverse(sps_ctx *c, int64_t *inv_dev) {
   if (!c || !inv_dev) return fail(SPS_ERR_INVALID, "null argument");
   HIP_TRY(hipSetDevice(c->device));
   const int n = (int)c->last_n;
+  HIP_TRY(hipDeviceSynchronize());  // the forward may still be running on a non-blocking stream
   if (n > 0) hipLaunchKernelGGL(k_i32_to_i64, dim3((n + 255) / 256), dim3(256), 0, 0, c->lv[0].inv, n, inv_dev);
   HIP_TRY(hipDeviceSynchronize());
   return SPS_OK;
@@ -1258,6 +1433,7 @@ int sps_get_parent(sps_ctx *c, int level, int32_t *parent_dev) {
 int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
   if (!c || !pairs_host || which < 0 || which > 5) return fail(SPS_ERR_INVALID, "bad arguments");
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipDeviceSynchronize());  // the forward may still be running on a non-blocking stream
   const int K = which == 5 ? 125 : 81;
   const int level = which == 5 ? 0 : which;
   if (which == 5 && !c->nbr5 && c->cap > 0) ALLOC(c->nbr5, int, 125 * c->cap);

@@ -6,6 +6,7 @@ argument order, return shapes and assertion messages.
 from __future__ import annotations
 
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -71,10 +72,12 @@ def prune(map_coords_feat=None, scan_coords_feat=None, ds=0.1):
         stream = torch.cuda.current_stream().cuda_stream
         ctx = models.get_context(dev, stream)
         mc32 = mc if (mc.dtype == torch.int32 and mc.stride(1) == 1) else mc.to(torch.int32).contiguous()
-        key = (mc.data_ptr(), tuple(mc.shape), mc._version)
-        if _MAP_CACHE.get(id(ctx)) != key:
+        # the uploaded hash belongs to THIS tensor object at THIS version (a different tensor that happens to be
+        # allocated at the same address must not hit the cache): weak reference + version counter
+        hit = _MAP_CACHE.get(id(ctx))
+        if hit is None or hit[0]() is not mc or hit[1] != mc._version:
             ctx.map_upload_voxels(mc32.data_ptr(), mc32.stride(0), mc32.shape[0], stream)
-            _MAP_CACHE[id(ctx)] = key
+            _MAP_CACHE[id(ctx)] = (weakref.ref(mc), mc._version)
         sc32 = sc if (sc.dtype == torch.int32 and sc.stride(1) == 1) else sc.to(torch.int32).contiguous()
         n = sc32.shape[0]
         out = torch.empty((n, 3), dtype=torch.float32, device=sc.device)
@@ -90,7 +93,12 @@ def add_timestamp(data, stamp, device):
 
 
 def infer(scan_points, submap_points, model, device="cuda"):
-    """util.py:163-184: [b=0 | scan xyz, t=1 ; submap xyz, t=0] -> model -> scores of the scan rows."""
+    """util.py:163-184: [b=0 | scan xyz, t=1 ; submap xyz, t=0] -> model -> scores of the scan rows.
+
+    Stream-ordered, no host synchronisation.  Contract for unrepresentable coordinates (outside the 64-bit voxel key,
+    include/sps_hip.h): their scores are NaN and the context's sticky error flag is set; it surfaces as SpsError
+    (SPS_ERR_RANGE) from the next synchronising call -- ``models.get_context(...).check_errors(stream)``,
+    ``SPSNet.step_metrics`` or ``StableFilter`` results -- never silently."""
     start_time = time.time()
     assert scan_points.size(-1) == 3, f"Expected 3 columns, but the scan tensor has {scan_points.size(-1)} columns."
     n_scan = len(scan_points)

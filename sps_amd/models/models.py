@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import math
 import os
-import weakref
 
 import numpy as np
 import torch
@@ -55,7 +54,7 @@ class NativeBackboneModule(nn.Module):
 
     def _init_backbone(self, out_channels: int) -> None:
         self.MinkUNet = CustomMinkUNet(in_channels=1, out_channels=out_channels, D=4)
-        self._loaded_ctxs = set()        # native contexts that currently hold this module's weights
+        self._dev_weights = {}           # device index -> _native.Weights holding this module's current parameters
         self._blob = None                # host copy of the weight blob in the native layout
         # any load_state_dict that reaches the backbone (predict.py:58 or util.py:39) re-uploads
         self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self.mark_weights_dirty())
@@ -63,32 +62,37 @@ class NativeBackboneModule(nn.Module):
     # ---- weights -> native blob ---------------------------------------------------------
     def mark_weights_dirty(self) -> None:
         """Call after modifying parameters in place; load_state_dict / .cuda() / .to() do it themselves."""
-        self._loaded_ctxs = set()
+        self._dev_weights = {}
         self._blob = None
 
     def _apply(self, fn, *args, **kwargs):
-        self._loaded_ctxs = set()
+        self._dev_weights = {}
         self._blob = None
         return super()._apply(fn, *args, **kwargs)
 
+    def device_weights(self, device_index: int) -> "_native.Weights":
+        """The device-resident weight set of the current parameters: packed, permuted and uploaded ONCE per device and
+        parameter version (sps_weights_create), then shared by every (device, stream) context."""
+        w = self._dev_weights.get(device_index)
+        if w is None:
+            oc = self.MinkUNet.out_channels
+            blob = self._blob
+            if blob is None:
+                sd = self.MinkUNet.state_dict()
+                blob = np.empty(_native.lib.sps_head_numel(oc), dtype=np.float32)
+                for name, off, numel in _native.weight_layout(oc):
+                    t = sd[name].detach().to("cpu", torch.float32).contiguous().reshape(-1)
+                    if t.numel() != numel:
+                        raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
+                    blob[off: off + numel] = t.numpy()
+                self._blob = blob
+            w = self._dev_weights[device_index] = _native.Weights(device_index, blob.ctypes.data, blob.size, oc)
+        return w
+
     def _sync_weights(self, ctx) -> None:
-        owner = getattr(ctx, "weights_owner", None)
-        if id(ctx) in self._loaded_ctxs and owner is not None and owner() is self:
-            return                       # this module's weights are the ones resident in ctx
-        oc = self.MinkUNet.out_channels
-        blob = self._blob
-        if blob is None:                 # packed once per parameter version, shared by every (device, stream) context
-            sd = self.MinkUNet.state_dict()
-            blob = np.empty(_native.lib.sps_head_numel(oc), dtype=np.float32)
-            for name, off, numel in _native.weight_layout(oc):
-                t = sd[name].detach().to("cpu", torch.float32).contiguous().reshape(-1)
-                if t.numel() != numel:
-                    raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
-                blob[off: off + numel] = t.numpy()
-            self._blob = blob
-        ctx.load_weights(blob.ctypes.data, blob.size, oc)
-        ctx.weights_owner = weakref.ref(self)   # a context is shared by every model on its device/stream
-        self._loaded_ctxs.add(id(ctx))
+        w = self.device_weights(ctx.device)
+        if ctx.weights is not w:         # a context is shared by every model on its device/stream
+            ctx.set_weights(w)           # O(1), no synchronisation
 
     @staticmethod
     def _prepare_coordinates(coordinates: torch.Tensor) -> torch.Tensor:

@@ -146,3 +146,42 @@ def small_scene(seed: int = 0, n_scan: int = 2000, extent: float = 6.0, voxel_si
     map_xyz = (scan_xyz + rng.normal(0, 0.03, scan_xyz.shape)).astype(np.float32)
     sub = submap_voxel_host(map_xyz, scan[:, :3], voxel_size)
     return assemble(scan, sub, 0)
+
+
+def make_nclt_scene(seed: int = 5, n_azimuth: int = 1000, voxel_size: float = 0.1, batch_index: int = 0):
+    """BASELINE config 4 (NCLT-like parking lot, SURVEY 8(d): "3x angular density or 3 merged scans -> ~300k active
+    voxels at tensor stride 1, map 5x larger"): three merged 128-beam scans taken 15 m apart, range 100 m, against a
+    map of 25 scan positions (5x the 5 of config 2).  ~500k rows, >= 300k active level-0 voxels."""
+    kw = dict(n_azimuth=n_azimuth, n_beams=128, max_range=100.0)
+    map_points = build_map(offsets=tuple(np.linspace(-24.0, 24.0, 25)), **kw)
+    scan = np.concatenate([lidar_scan(10 * seed + i, x_offset=x, **kw) for i, x in enumerate((-15.0, 0.0, 15.0))], 0)
+    sub = submap_voxel_host(map_points[:, :3], scan[:, :3], voxel_size)
+    return dict(batch=assemble(scan, sub, batch_index), scan=scan, map=map_points, n_scan=len(scan))
+
+
+def sequence_map(n_scans: int, step: float = 0.5, spacing: float = 2.0, **kw) -> np.ndarray:
+    """Map for a config-3 sequence: scans every ``spacing`` m along the sensor path (x = 0 .. n_scans * step)."""
+    xs = np.arange(-4.0, n_scans * step + 4.0 + 1e-9, spacing)
+    return build_map(offsets=tuple(xs), **kw)
+
+
+def make_sequence(n_scans: int, step: float = 0.5, first_seed: int = 100, voxel_size: float = 0.1,
+                  map_points: np.ndarray | None = None, **kw):
+    """BASELINE config 3: consecutive scans, the sensor advancing ``step`` m per scan along x; yields [N,6] batches
+    (b = 0) in the layout of BacchusDataset.__getitem__ + collate_fn."""
+    if map_points is None:
+        map_points = sequence_map(n_scans, step, **kw)
+    for i in range(n_scans):
+        scan = lidar_scan(first_seed + i, x_offset=step * i, **kw)
+        sub = submap_voxel_host(map_points[:, :3], scan[:, :3], voxel_size)
+        yield assemble(scan, sub, 0)
+
+
+def collate(items, ) -> np.ndarray:
+    """BacchusModule.collate_fn (blt_dataset.py:173-182) on numpy [n_i, 6] batches: batch column = position in the list."""
+    out = []
+    for b, it in enumerate(items):
+        q = it.copy()
+        q[:, 0] = b
+        out.append(q)
+    return np.concatenate(out, 0)

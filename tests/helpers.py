@@ -30,3 +30,41 @@ def net_from_params(params: dict, cfg: dict = CFG):
     net = SPSNet(cfg)
     net.load_state_dict(state_dict_from_params(params))     # strict: same keys as the reference
     return net
+
+
+LOGIT_EPS = float(np.log(0.84 / 0.16))      # sigmoid(LOGIT_EPS) = 0.84 = FILTER.THRESHOLD
+
+
+def straddle_params(params: dict, batch: np.ndarray, frac: float = 0.3, gain: float = 8.0,
+                    eps: float = 0.84) -> dict:
+    """Copy of ``params`` whose `final` layer is rescaled (kernel x gain, bias shifted) so that about ``frac``
+    of the scan scores of ``batch`` are >= eps.  With plain Kaiming weights no synthetic score ever reaches
+    0.84 (they stay in [0.16, 0.77]) and every label / TP / FP / dIoU comparison would be 0 == 0.
+    Uses the C oracle (test infrastructure) to find the logit quantile."""
+    from oracle import c_oracle
+    _, info = c_oracle.forward(c_oracle.pack_blob(params), batch[:, :5], CFG["MODEL"]["VOXEL_SIZE"], nthreads=8)
+    logits = info["logits"][info["inverse"]][batch[:, 4] == 1].astype(np.float64)
+    b0 = float(np.asarray(params["final.bias"]).reshape(-1)[0])
+    q = float(np.quantile(gain * (logits - b0), 1.0 - frac))
+    out = dict(params)
+    out["final.kernel"] = (np.asarray(params["final.kernel"]) * np.float32(gain)).astype(np.float32)
+    out["final.bias"] = np.full_like(np.asarray(params["final.bias"]), np.log(eps / (1.0 - eps)) - q)
+    return out
+
+
+def plant_threshold_labels(batch: np.ndarray, eps: float = 0.84, every: int = 7) -> np.ndarray:
+    """Copy of ``batch`` [N,6] in which every ``every``-th scan row's label is exactly float32(eps), the float32
+    just below or the float32 just above it (the reference thresholds with `<` on float32, models.py:97-98, so
+    label == eps is class 1 and the neighbour below is class 0)."""
+    e = np.float32(eps)
+    vals = np.array([e, np.nextafter(e, np.float32(0)), np.nextafter(e, np.float32(1))], np.float32)
+    out = batch.copy()
+    rows = np.flatnonzero(out[:, 4] == 1)[::every]
+    out[rows, 5] = vals[np.arange(len(rows)) % 3]
+    return out
+
+
+def assert_nondegenerate(sums) -> None:
+    """[count, TP, FP, FN, TN, ...]: every confusion cell must be populated, else a label comparison is vacuous."""
+    s = np.asarray(sums, dtype=np.float64).reshape(-1, 8).sum(axis=0)
+    assert s[1] > 0 and s[2] > 0 and s[3] > 0 and s[4] > 0, f"degenerate confusion counts TP/FP/FN/TN = {s[1:5]}"

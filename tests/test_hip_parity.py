@@ -7,7 +7,7 @@ import torch
 
 from oracle import sps_oracle as O
 from sps_amd import synthetic
-from tests.helpers import CFG, net_from_params
+from tests.helpers import CFG, assert_nondegenerate, net_from_params, plant_threshold_labels, straddle_params
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +17,9 @@ EPS = CFG["FILTER"]["THRESHOLD"]
 
 @pytest.fixture(scope="module")
 def params():
-    return O.random_params(seed=0)
+    """Seed-0 synthetic weights with `final` rescaled so that ~30 % of the scan scores are >= eps = 0.84 (25-30 % on
+    every scene used below): labels, TP / FP / FN / TN and dIoU are compared in the regime where both classes occur."""
+    return straddle_params(O.random_params(seed=0), synthetic.small_scene(seed=11, n_scan=2500))
 
 
 @pytest.fixture(scope="module")
@@ -71,7 +73,7 @@ def match_rows(got: np.ndarray, want: np.ndarray) -> np.ndarray:
     return perm
 
 
-def check_full(net, params, batch, tol=2e-4):
+def check_full(net, params, batch, tol=2e-4, both_classes=False):
     dev, scores = run(net, batch)
     ref, info = O.sps_forward(params, batch[:, :5], VS, keep=True)
     counts = ctx().level_counts()
@@ -109,11 +111,14 @@ def check_full(net, params, batch, tol=2e-4):
     e = np.float32(EPS)
     band = np.abs(ref - e) > 1e-5
     np.testing.assert_array_equal((s < e)[band], (ref < e)[band])
+    if both_classes:
+        # not a comparison of all-stable with all-stable: both labels occur, on both sides
+        assert 0.05 < (ref[band] >= e).mean() < 0.95, "degenerate label distribution"
     return dev, s, ref
 
 
 def test_small_scene_full_parity(net, params):
-    check_full(net, params, synthetic.small_scene(seed=0, n_scan=2000))
+    check_full(net, params, synthetic.small_scene(seed=0, n_scan=2000), both_classes=True)
 
 
 def test_other_seed_and_default_bn(params):
@@ -126,19 +131,66 @@ def test_negative_octants_and_requantised_corners(net, params):
     """Submap rows are voxel corners ix*0.1f that re-quantise to ix-1 for some negatives (App. E)."""
     b = synthetic.small_scene(seed=2, n_scan=1200, extent=4.0)
     b[:, 1:4] -= 7.3
-    check_full(net, params, b)
+    check_full(net, params, b, both_classes=True)
+
+
+def oracle_confusion(scores, batch):
+    """[TP, FP, FN, TN] over the scan rows with the reference's rule (models.py:97-98: `<` on float32)."""
+    scan = batch[:, 4] == 1
+    e = np.float32(EPS)
+    pred = scores[scan].astype(np.float32) >= e
+    gt = batch[scan, 5].astype(np.float32) >= e
+    return np.array([(gt & pred).sum(), (~gt & pred).sum(), (gt & ~pred).sum(), (~gt & ~pred).sum()], np.float64)
 
 
 def test_metrics_match_oracle(net, params):
-    batch = synthetic.small_scene(seed=11, n_scan=2500)
-    dev, s, ref = check_full(net, params, batch)
+    """predict_step vs the oracle in the regime where pred == 1 and gt == 1 both occur (TP, FP, FN, TN > 0), with
+    labels planted exactly at / one ulp around eps."""
+    batch = plant_threshold_labels(synthetic.small_scene(seed=11, n_scan=2500))
+    dev, s, ref = check_full(net, params, batch, both_classes=True)
     m = net.predict_step(dev, 0)
+    assert_nondegenerate([m["count"], m["tp"], m["fp"], m["fn"], m["tn"], 0, 0, 0])
+    assert min(m["precision"], m["recall"], m["f1"], m["dIoU"]) > 0
+    np.testing.assert_array_equal([m["tp"], m["fp"], m["fn"], m["tn"]], oracle_confusion(s, batch))
     mo = O.predict_metrics(s, batch, EPS)          # same scores -> counts must be exact
     for k in ("precision", "recall", "f1", "accuracy", "dIoU"):
         assert m[k] == pytest.approx(mo[k], abs=1e-12), k
     assert m["loss"] == pytest.approx(mo["loss"], rel=1e-9)
     assert m["r2"] == pytest.approx(mo["r2"], rel=1e-8)
     assert net.dIoU[-1] == m["dIoU"] and len(net.predict_loss) >= 1
+    # against the ORACLE's scores: the confusion counts may differ only by rows whose score lies within 1e-5 of eps
+    n_band = int((np.abs(ref[batch[:, 4] == 1] - np.float32(EPS)) <= 1e-5).sum())
+    assert np.abs(np.array([m["tp"], m["fp"], m["fn"], m["tn"]]) - oracle_confusion(ref, batch)).max() <= n_band
+    mr = O.predict_metrics(ref, batch, EPS)
+    assert m["dIoU"] == pytest.approx(mr["dIoU"], abs=(n_band + 1e-9) / max(m["tp"] + m["fp"] + m["fn"], 1))
+    assert m["loss"] == pytest.approx(mr["loss"], abs=1e-6)
+
+
+def test_threshold_ties_scores_and_labels(net):
+    """sps_metrics on hand-made scores: score == eps is class 1 (`score < eps ? 0 : 1` in float32, models.py:97), the
+    float32 below it class 0; the same for labels; eps itself is the float32 rounding of the config's 0.84."""
+    e = np.float32(EPS)
+    lo, hi = np.nextafter(e, np.float32(0)), np.nextafter(e, np.float32(1))
+    vals = np.array([e, lo, hi, 0.0, 1.0, 0.5], np.float32)
+    sc, lb = np.meshgrid(vals, vals, indexing="ij")
+    n = sc.size
+    batch = np.zeros((n + 3, 6), np.float32)
+    batch[:n, 4] = 1
+    batch[:n, 5] = lb.ravel()
+    batch[n:, 5] = 1.0                                  # map rows (t = 0) never count
+    scores = np.concatenate([sc.ravel(), np.ones(3, np.float32)])
+    dev, sd = torch.from_numpy(batch).cuda(), torch.from_numpy(scores).cuda()
+    got = np.asarray(net.step_metrics(dev, sd, 1), np.float64)[0]
+    assert got[0] == n
+    np.testing.assert_array_equal(got[1:5], oracle_confusion(scores, batch))
+    assert_nondegenerate(got)
+    pred = np.where(sc.ravel() < e, 0, 1)
+    assert pred[:6].tolist() == [1] * 6 and pred[6:12].tolist() == [0] * 6      # score == eps -> 1, just below -> 0
+    want = O.predict_metrics(scores, batch, EPS)
+    from sps_amd.models.models import metrics_from_sums
+    mg = metrics_from_sums(got)
+    for k in ("precision", "recall", "f1", "accuracy", "dIoU"):
+        assert mg[k] == pytest.approx(want[k], abs=1e-12), k
 
 
 def test_batch_independence(net, params):
@@ -158,6 +210,8 @@ def test_batch_independence(net, params):
     # same terms per row; only the f32 summation grouping may differ with the tile composition
     np.testing.assert_allclose(s.cpu().numpy(), np.concatenate(singles), rtol=0, atol=2e-6)
     per = net.step_metrics(dev, s, n_batches=3)
+    for i in range(3):
+        assert_nondegenerate(per[i])
     for i, p in enumerate(parts):
         sb = s.cpu().numpy()[sum(len(q) for q in parts[:i]): sum(len(q) for q in parts[:i + 1])]
         mo = O.predict_metrics(sb, p, EPS)
@@ -274,7 +328,7 @@ def test_infer_helper(net, params):
 def test_config2_full_size_parity(net, params):
     """BASELINE config 2 (~100k-pt scan + submap, 0.1 m): full oracle comparison."""
     sc = synthetic.make_scene(scan_seed=1)
-    check_full(net, params, sc["batch"], tol=5e-4)
+    check_full(net, params, sc["batch"], tol=5e-4, both_classes=True)
 
 
 def test_lightning_checkpoint_roundtrip(tmp_path, params):
@@ -298,7 +352,7 @@ def test_config3_batch4_streamed(net, params):
     """BASELINE config 3: batch = 4 scans in one tensor (collate layout), per-scan metric rows."""
     from sps.datasets.blt_dataset import BacchusModule
     from sps_amd.models.models import metrics_from_sums
-    items = [torch.from_numpy(synthetic.small_scene(seed=60 + i, n_scan=2500)[:, 1:]) for i in range(4)]
+    items = [torch.from_numpy(plant_threshold_labels(synthetic.small_scene(seed=60 + i, n_scan=2500))[:, 1:]) for i in range(4)]
     batch = BacchusModule.collate_fn(items)                       # [sum N, 6] with b = 0..3
     dev = batch.cuda()
     s = net(dev)
@@ -309,6 +363,8 @@ def test_config3_batch4_streamed(net, params):
     np.testing.assert_allclose(sc, ref, rtol=0, atol=1e-4)
     for i in range(4):
         rows = b[:, 0] == i
+        assert_nondegenerate(per[i])
+        np.testing.assert_array_equal(per[i][1:5], oracle_confusion(sc[rows], b[rows]))
         mo = O.predict_metrics(sc[rows], b[rows], EPS)
         mg = metrics_from_sums(per[i])
         for k in ("precision", "recall", "f1", "accuracy", "dIoU"):
@@ -335,6 +391,10 @@ def test_config4_nclt_size_properties(net, params):
     e = np.float32(EPS)
     band = np.abs(ref - e) > 1e-5
     np.testing.assert_array_equal((sg < e)[band], (ref < e)[band])
+    assert 0.05 < (ref[band] >= e).mean() < 0.95, "degenerate label distribution"
+    sums = np.asarray(net.step_metrics(dev, s, 1), np.float64)[0]
+    assert_nondegenerate(sums)
+    np.testing.assert_array_equal(sums[1:5], oracle_confusion(sg, batch))
     # points of one voxel share one score (App. A.15): scores are a function of the inverse map
     from sps_amd import _native
     inv = torch.empty(len(batch), dtype=torch.int64, device="cuda")
@@ -480,7 +540,8 @@ def test_structured_stress_cases(net, params, kind):
 def test_fused_forward_metrics_matches_separate_calls(net, params):
     """sps_forward_metrics = sps_forward + sps_metrics_dev: identical scores, identical confusion counts, float sums to
     rounding (the accumulation order of the f64 atomics differs); also with several batch indices and empty input."""
-    scenes = [synthetic.make_scene(scan_seed=11 + i, n_azimuth=300, batch_index=i)["batch"] for i in range(3)]
+    scenes = [plant_threshold_labels(synthetic.make_scene(scan_seed=11 + i, n_azimuth=300, batch_index=i)["batch"])
+              for i in range(3)]
     for nb, arr in ((1, scenes[0]), (3, np.concatenate(scenes, 0))):
         dev = torch.from_numpy(arr).cuda()
         s_ref = net(dev)
@@ -491,7 +552,12 @@ def test_fused_forward_metrics_matches_separate_calls(net, params):
         assert out.data_ptr() == table[1].data_ptr() and (table[0] == -1).all()
         assert torch.equal(s_fused, s_ref)
         got = out.cpu().numpy()
+        for row in got:
+            assert_nondegenerate(row)
         np.testing.assert_array_equal(got[:, :5], sums_ref[:, :5])                 # count, TP, FP, FN, TN
+        for b in range(nb):
+            rows = arr[:, 0] == b
+            np.testing.assert_array_equal(got[b, 1:5], oracle_confusion(s_ref.cpu().numpy()[rows], arr[rows]))
         np.testing.assert_allclose(got[:, 5:], sums_ref[:, 5:], rtol=1e-12, atol=1e-9)
         want = O.predict_metrics(s_ref.cpu().numpy(), arr, EPS)
         m = metrics_from_all(got)
