@@ -86,12 +86,14 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
         loader = data.test_dataloader()
     n_scans = len(loader)
 
+    if not weights:
+        torch.manual_seed(0)                       # reproducible random init (the same on every rank)
     model = models.SPSNet(cfg, n_scans)
     if weights:
         ckpt = torch.load(weights, map_location="cpu", weights_only=False)
         model.load_state_dict(ckpt["state_dict"])
     else:
-        print("no --weights given: random-init weights (resnet.py:87-94 scheme)")
+        print("no --weights given: random-init weights (resnet.py:87-94 scheme, torch.manual_seed(0))")
     model = model.to(dev).eval().freeze()
 
     # The reference's loop (predict.py:64-67: trainer.predict -> predict_step per scan, three host syncs each) as a

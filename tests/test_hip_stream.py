@@ -1,0 +1,245 @@
+"""GPU tests of the stream-ordered pieces around the forward: the pose transform (a1), the device-count forward, the
+epsilon-filter compaction (f2), the pipelined ScanEngine that bench.py and scripts/predict.py run, and the multi-rank
+bench control flow.  All through the C ABI (ctypes bindings of include/sps_hip.h)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sps_oracle as O
+from sps_amd import synthetic
+from tests.helpers import CFG, assert_nondegenerate, net_from_params, plant_threshold_labels, straddle_params
+
+pytestmark = pytest.mark.gpu
+
+VS = CFG["MODEL"]["VOXEL_SIZE"]
+EPS = CFG["FILTER"]["THRESHOLD"]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def params():
+    return straddle_params(O.random_params(seed=0), synthetic.small_scene(seed=11, n_scan=2500))
+
+
+@pytest.fixture(scope="module")
+def net(params):
+    return net_from_params(params).cuda().eval().freeze()
+
+
+def ctx():
+    from sps_amd.models.models import get_context
+    return get_context(0)
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def test_transform_points_bit_exact_vs_reference_goldens():
+    """util.transform_point_cloud on the device against vectors captured from the reference (tools/capture_goldens.py):
+    float64 results bit for bit (same fused multiply-add chain as numpy's dgemm), float32 store, float32 input,
+    strided input/output, perspective matrix, identity."""
+    z = np.load(os.path.join(GOLD, "transform.npz"))
+    pts = z["pts"]
+    n = len(pts)
+    for T, want in ((z["T"], z["out_T"]), (z["P"], z["out_P"])):
+        src = torch.from_numpy(pts).cuda()
+        out64 = torch.empty((n, 3), dtype=torch.float64, device="cuda")
+        ctx().transform_points(src.data_ptr(), True, 3, n, T, out64.data_ptr(), True, 3, stream())
+        np.testing.assert_array_equal(out64.cpu().numpy(), want)
+        out32 = torch.zeros((n, 7), dtype=torch.float32, device="cuda")               # strided output rows
+        ctx().transform_points(src.data_ptr(), True, 3, n, T, out32.data_ptr() + 8, False, 7, stream())
+        np.testing.assert_array_equal(out32[:, 2:5].cpu().numpy(), want.astype(np.float32))
+        assert (out32[:, :2] == 0).all() and (out32[:, 5:] == 0).all()
+        # float32 input in a wider row (a LiDAR driver's x,y,z,intensity): the reference widens to float64 first
+        p32 = np.zeros((n, 4), np.float32)
+        p32[:, :3] = pts.astype(np.float32)
+        from sps_amd.datasets import util
+        ref32 = util.transform_point_cloud(p32[:, :3].astype(np.float64), T)
+        ctx().transform_points(torch.from_numpy(p32).cuda().data_ptr(), False, 4, n, T, out64.data_ptr(), True, 3, stream())
+        np.testing.assert_array_equal(out64.cpu().numpy(), ref32)
+    ctx().transform_points(src.data_ptr(), True, 3, n, None, out64.data_ptr(), True, 3, stream())
+    np.testing.assert_array_equal(out64.cpu().numpy(), pts)
+    ctx().transform_points(src.data_ptr(), True, 3, 0, z["T"], out64.data_ptr(), True, 3, stream())   # empty: no launch
+
+
+def test_forward_with_device_side_row_count(net, params):
+    """sps_forward_n: the row count comes from device memory (<= the bound the grids were sized for); identical bits."""
+    batch = synthetic.small_scene(seed=17, n_scan=2600)
+    n = len(batch)
+    dev = torch.from_numpy(batch).cuda()
+    want = net(dev)
+    padded = torch.full((2 * n, 6), 7.5e8, dtype=torch.float32, device="cuda")   # rows past the count are never read
+    padded[:n] = dev
+    for count in (n, n - 777):
+        cnt = torch.tensor([3, 4, count, 5], dtype=torch.int32, device="cuda")
+        scores = torch.full((2 * n,), -3.0, dtype=torch.float32, device="cuda")
+        net.model._sync_weights(ctx())
+        ctx().forward_n(padded.data_ptr(), 6, 2 * n, cnt.data_ptr() + 8, VS, scores.data_ptr(), stream())
+        ctx().check_errors(stream())                                             # no range error from the padding rows
+        assert (scores[count:] == -3.0).all()
+        ref = want if count == n else net(dev[:count])
+        assert torch.equal(scores[:count], ref)
+        assert ctx().level_counts()[0] == len(np.unique(O.quantize(batch[:count, :5], VS), axis=0))
+
+
+def test_compact_stable_keeps_order_and_drops_nan(net):
+    rng = np.random.default_rng(3)
+    n = 70_001                                              # several SCAN_BLOCK chunks + a ragged tail
+    e = np.float32(EPS)
+    s = rng.uniform(0, 1, n).astype(np.float32)
+    s[::11] = e                                             # ties: kept (`<=`, sps_node.py:148)
+    s[1::11] = np.nextafter(e, np.float32(1))               # just above: dropped
+    s[5::97] = np.nan
+    rows = rng.normal(size=(n, 4)).astype(np.float32)
+    out = torch.full((n, 3), -1.0, dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ctx().compact_stable(torch.from_numpy(s).cuda().data_ptr(), torch.from_numpy(rows).cuda().data_ptr(), 4, 3, n, EPS,
+                         out.data_ptr(), cnt.data_ptr(), stream())
+    keep = s <= e
+    assert int(cnt.item()) == int(keep.sum()) and 0 < keep.sum() < n
+    np.testing.assert_array_equal(out[: int(cnt.item())].cpu().numpy(), rows[keep, :3])
+    assert (out[int(cnt.item()):] == -1).all()
+    ctx().compact_stable(0, 0, 4, 3, 0, EPS, out.data_ptr(), cnt.data_ptr(), stream())
+    assert int(cnt.item()) == 0
+
+
+def test_streaming_filter_is_stream_ordered_and_matches_oracle(net, params):
+    """sps_node.callback minus ROS on several scans issued back to back (no host synchronisation between them), float64
+    and float32 input, with and without pose; checked against the oracle's stages."""
+    from sps_amd.pipeline import StableFilter
+    import sps.datasets.util as util
+    map_pts = synthetic.build_map(n_azimuth=400, n_beams=32)
+    f = StableFilter(net, torch.from_numpy(map_pts), voxel_size=VS, epsilon=EPS)
+    ang = 0.4
+    pose = np.array([[np.cos(ang), -np.sin(ang), 0, 1.0], [np.sin(ang), np.cos(ang), 0, -0.5], [0, 0, 1, 0.0], [0, 0, 0, 1.0]])
+    cases = []
+    for i, (dtype, use_pose) in enumerate(((np.float64, True), (np.float32, True), (np.float32, False))):
+        world = synthetic.lidar_scan(77 + i, x_offset=1.0 - i, n_azimuth=400, n_beams=32)[:, :3].astype(np.float64)
+        sensor = (util.inverse_transform_point_cloud(world, pose) if use_pose else world).astype(dtype)
+        cases.append((sensor, pose if use_pose else None))
+    pending = [f.submit(sensor, p) for sensor, p in cases]                  # three scans in flight, nothing synchronised
+    any_kept = any_dropped = False
+    for (sensor, p), pend in zip(cases, pending):
+        res = pend.result()
+        world = sensor.astype(np.float64) if p is None else util.transform_point_cloud(sensor.astype(np.float64), p)
+        world = world.astype(np.float32)
+        sub, n_sv = O.prune(O.to_coords(map_pts[:, :3], VS), O.to_coords(world, VS), VS)
+        assert (res.n_scan_voxels, res.n_submap_voxels) == (n_sv, len(sub))
+        batch = synthetic.assemble(np.c_[world, np.zeros(len(world))].astype(np.float32), sub)
+        ref, _ = O.sps_forward(params, batch[:, :5], VS)
+        n = len(world)
+        got = res.scores.cpu().numpy()
+        assert got.shape == (n,)
+        np.testing.assert_allclose(got, ref[:n], rtol=0, atol=1e-4)
+        band = np.abs(ref[:n] - np.float32(EPS)) > 1e-5
+        got_keep = got <= np.float32(EPS)
+        np.testing.assert_array_equal(got_keep[band], (ref[:n] <= np.float32(EPS))[band])
+        assert res.filtered.shape == (int(got_keep.sum()), 3)
+        np.testing.assert_array_equal(res.filtered.cpu().numpy(), sensor[got_keep].astype(np.float32))   # as received
+        any_kept |= bool(got_keep.any())
+        any_dropped |= bool((~got_keep).any())
+        assert res.t_total > 0 and res.t_prune > 0 and res.t_infer > 0
+    assert any_kept and any_dropped                              # the filter removed some points and kept others
+    # an unrepresentable coordinate surfaces at result(), not silently as a dropped point
+    from sps_amd._native import SpsError
+    bad = cases[2][0].copy()
+    bad[0, 0] = 3.0e4
+    with pytest.raises(SpsError):
+        f(bad)
+    f(cases[2][0])                                               # the flag was cleared: the next scan is fine
+
+
+def test_scan_engine_matches_per_scan_predict_step(net, params):
+    """The pipelined loop (bench.py / scripts/predict.py) == the reference-shaped per-scan loop: same scores, same
+    confusion counts per scan, fed from device tensors, from pinned host tensors and from pageable host tensors."""
+    from sps_amd.engine import ScanEngine, per_scan_metrics
+    scans = [plant_threshold_labels(synthetic.small_scene(seed=80 + i, n_scan=1800 + 100 * i)) for i in range(9)]
+    want = []
+    for b in scans:
+        want.append(net.predict_step(torch.from_numpy(b).cuda(), 0))
+    eng = ScanEngine(net, 0, streams=4, max_rows=max(len(b) for b in scans), table_rows=len(scans))
+    feeds = {"device": [torch.from_numpy(b).cuda() for b in scans],
+             "pinned": [torch.from_numpy(b).pin_memory() for b in scans],
+             "pageable": [torch.from_numpy(b) for b in scans]}
+    torch.cuda.synchronize()
+    for name, feed in feeds.items():
+        sums = eng.run_sequence(feed)
+        assert sums.shape == (len(scans), 8)
+        for row, w in zip(sums, want):
+            assert_nondegenerate(row)
+            np.testing.assert_array_equal(row[:5], [w["count"], w["tp"], w["fp"], w["fn"], w["tn"]])
+        for m, w in zip(per_scan_metrics(sums), want):
+            assert m["dIoU"] == pytest.approx(w["dIoU"], abs=1e-12) and m["loss"] == pytest.approx(w["loss"], rel=1e-9), name
+    # batch = 4 per step (config 3 layout): per-scan rows unchanged
+    groups = [synthetic.collate(scans[i: i + 4]) for i in (0, 4)]
+    eng.reset_table(8)
+    last = None
+    for g in groups:
+        last = eng.submit(torch.from_numpy(g).pin_memory(), 4)
+    sums4 = eng.finish().cpu().numpy()
+    for row, w in zip(sums4, want[:8]):
+        np.testing.assert_array_equal(row[:5], [w["count"], w["tp"], w["fp"], w["fn"], w["tn"]])
+    assert last.shape == (len(groups[1]),)
+    with pytest.raises(ValueError, match="metric table too small"):
+        eng.submit(feeds["device"][0], 1, row=eng.table.shape[0])
+
+
+def _run(cmd, timeout=900):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+
+
+@pytest.mark.timeout(1200)
+def test_bench_two_ranks_on_one_gpu_gloo():
+    """The N > 1 control flow of bench.py (rank/world from the environment, per-rank engines, the metric all-gather
+    inside the timed region, max-over-ranks timing, one JSON line from rank 0), launched exactly as the driver does but
+    with the gloo backend so that two ranks can share the one GPU of this box.  Child processes: the parent test
+    process never hands its GPU state to them."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+              "--master-port", "29531", "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "12", "--warmup", "3",
+              "--azimuth", "500", "--streams", "3", "--no-cpu-baseline", "--no-stages"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 3 and d["scaling"] == "weak"
+    assert d["value"] == pytest.approx(2 * 12 / (d["ms_per_step"] * 12e-3), rel=1e-3)         # whole-job scans/s
+    assert d["config"]["sharding"] == "dp2" and d["mean_metrics"]["dIoU"] > 0
+    assert d["h2d_inclusive"]["value"] > 0 and d["roofline"]["frac"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_bench_driver_protocol_is_steady_state():
+    """`--steps 20 --warmup 5` (what the driver runs): nothing but steady-state work inside the timed region, so the
+    short run stays close to a longer one (pipeline fill/drain is all that separates them)."""
+    out = {}
+    for k, w in ((20, 5), (200, 20)):
+        r = _run([sys.executable, "bench.py", "--steps", str(k), "--warmup", str(w), "--no-cpu-baseline", "--no-stages",
+                  "--no-h2d"])
+        assert r.returncode == 0, r.stderr[-3000:]
+        out[k] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out[20]["config"]["streams_per_gpu"] == 20           # clamped to the step count
+    assert out[20]["value"] > 0.75 * out[200]["value"], (out[20]["value"], out[200]["value"])
+    assert out[20]["mean_metrics"]["dIoU"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_predict_cli_pipelined_matches_bench_loop():
+    """scripts/predict.py --synthetic runs the engine loop: six metric lines + a timing line, batch 1 and batch 4 give the
+    same per-scan means."""
+    outs = []
+    for bs in ("1", "4"):
+        r = _run([sys.executable, os.path.join("scripts", "predict.py"), "--synthetic", "8", "-c", os.path.join("config", "config.yaml"),
+                  "--batch-size", bs, "--timing", "--streams", "3"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = {l.split(" ")[0]: l for l in r.stdout.splitlines()}
+        assert "timing:" in lines, r.stdout
+        outs.append([lines[k] for k in ("Loss", "R2", "dIoU", "Precision", "Recall", "F1")])
+    assert outs[0] == outs[1]
