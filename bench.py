@@ -188,7 +188,7 @@ def main():
 
     # ---- engine: arena + shared weights + one forward per context, all before the timed region -------------------
     S = max(1, min(args.streams, K))
-    eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb)
+    eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb, stage_cols=0 if args.no_h2d else 6)
     streams = eng.streams
     main_stream = eng.main
 

@@ -8,6 +8,10 @@ _ALIASES = {
     "sps.models": "sps_amd.models",
     "sps.models.models": "sps_amd.models.models",
     "sps.models.minkunet": "sps_amd.models.minkunet",
+    # the reference imports the backbone class from here (src/sps/models/models.py:10, c_ws/src/mos4d/scripts/mos4d.py:9)
+    "sps.models.MinkowskiEngine": "sps_amd.models",
+    "sps.models.MinkowskiEngine.customminkunet": "sps_amd.models.minkunet",
+    "sps.models.MinkowskiEngine.minkunet": "sps_amd.models.minkunet",
     "sps.datasets": "sps_amd.datasets",
     "sps.datasets.util": "sps_amd.datasets.util",
     "sps.datasets.blt_dataset": "sps_amd.datasets.blt_dataset",

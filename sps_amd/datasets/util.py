@@ -5,6 +5,7 @@ argument order, return shapes and assertion messages.
 """
 from __future__ import annotations
 
+import os
 import time
 import weakref
 
@@ -38,6 +39,23 @@ def load_model(cfg=None, weights_pth=None, device="cuda"):
     model.eval()
     model.freeze()
     return model
+
+
+def load_point_cloud_map(cfg):
+    """util.py:49-64: $DATA/maps/<TRAIN.MAP> (.npy, else text) -> float32 [M, 3] tensor.  The reference logs through
+    rospy and calls sys.exit() on failure; without ROS the logging is `print` and the failure an exception."""
+    assert cfg != None, "cfg is None!"
+    map_id = cfg["TRAIN"]["MAP"]
+    map_pth = os.path.join(str(os.environ.get("DATA")), "maps", map_id)
+    __, file_extension = os.path.splitext(map_pth)
+    print('Loading point cloud map, pth: %s' % (map_pth))
+    try:
+        point_cloud_map = np.load(map_pth) if file_extension == '.npy' else np.loadtxt(map_pth, dtype=np.float32)
+        point_cloud_map = torch.tensor(point_cloud_map[:, :3]).to(torch.float32).reshape(-1, 3)
+    except Exception as e:
+        raise RuntimeError('Failed to load point cloud map from %s' % map_pth) from e
+    print('Point cloud map loaded successfully with %d points' % len(point_cloud_map))
+    return point_cloud_map
 
 
 def to_coords_features(cloud, feature_type='map', ds=0.1, device="cuda"):

@@ -25,7 +25,7 @@ DEFAULT_STREAMS = 23      # the HIP runtime multiplexes streams onto 4 hardware 
 
 class ScanEngine:
     def __init__(self, net: SPSNet, device: torch.device | int | None = None, streams: int = DEFAULT_STREAMS,
-                 max_rows: int = 0, table_rows: int = 0):
+                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0):
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
@@ -43,12 +43,13 @@ class ScanEngine:
         self._pinned = [None] * S
         self.table = None
         self.rows_used = 0
-        self.prepare(max_rows, table_rows)
+        self.prepare(max_rows, table_rows, stage_cols)
 
     # ---- set-up: everything that is not steady state happens here ------------------------------------------------
-    def prepare(self, max_rows: int = 0, table_rows: int = 0) -> None:
+    def prepare(self, max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0) -> None:
         """Arena of every context sized for ``max_rows`` points, the shared weight set attached, one tiny forward per
-        context (first-use costs: code objects, events) -- so that the first timed scan is already steady state."""
+        context (first-use costs: code objects, events), and -- when batches will arrive as host tensors with
+        ``stage_cols`` columns -- the per-stream device staging buffers: the first timed scan is already steady state."""
         with torch.cuda.device(self.device):
             w = self.net.model.device_weights(self.index)
             warm = torch.zeros((64, 6), dtype=torch.float32, device=self.device)
@@ -64,6 +65,10 @@ class ScanEngine:
                     self.net.forward_metrics(warm, 1, out)
             if table_rows:
                 self.reset_table(table_rows)
+            if stage_cols and max_rows:
+                for k, st in enumerate(self.streams):
+                    with torch.cuda.stream(st):
+                        self._stage[k] = torch.empty((int(max_rows), int(stage_cols)), dtype=torch.float32, device=self.device)
             torch.cuda.synchronize(self.device)
 
     def reset_table(self, rows: int) -> None:
@@ -100,8 +105,9 @@ class ScanEngine:
         if buf is None or buf.shape[0] < n or buf.shape[1] != host.shape[1]:
             cap = max(n, 1024)
             buf = self._stage[k] = torch.empty((cap + cap // 4, host.shape[1]), dtype=torch.float32, device=self.device)
-            self._pinned[k] = torch.empty((cap + cap // 4, host.shape[1]), dtype=torch.float32).pin_memory()
         if not host.is_pinned():
+            if self._pinned[k] is None or self._pinned[k].shape[0] < n or self._pinned[k].shape[1] != host.shape[1]:
+                self._pinned[k] = torch.empty((max(n, buf.shape[0]), host.shape[1]), dtype=torch.float32).pin_memory()
             # the stream's previous copy out of this pinned buffer must be done before it is overwritten
             self.streams[k].synchronize()
             self._pinned[k][:n].copy_(host)

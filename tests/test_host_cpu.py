@@ -207,3 +207,29 @@ def test_bacchus_module_reads_data_tree(tmp_path, monkeypatch):
     with pytest.raises(AssertionError, match="should be the same"):
         os.remove(sorted((tmp_path / "sequence" / "20220629" / "poses").iterdir())[0])
         blt.BacchusModule(cfg, test=True)
+
+
+def test_reference_module_paths_and_map_loader(tmp_path, monkeypatch):
+    """The import paths the reference's callers use (src/sps/models/models.py:10, c_ws/src/mos4d/scripts/mos4d.py:9,
+    c_ws/src/sps_filter/scripts/sps_node.py:69) resolve to the drop-in package; util.load_point_cloud_map reads
+    $DATA/maps/<TRAIN.MAP> as the reference does (.npy and text), float32 [M, 3]."""
+    from sps.models.MinkowskiEngine.customminkunet import CustomMinkUNet
+    from sps_amd.models.minkunet import CustomMinkUNet as Native
+    assert CustomMinkUNet is Native
+    m = CustomMinkUNet(in_channels=1, out_channels=3, D=4)
+    assert m.state_dict()["final.kernel"].shape == (8, 3)
+    import sps.datasets.util as util
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(50, 4))
+    os.makedirs(tmp_path / "maps")
+    np.save(tmp_path / "maps" / "base_map.asc.npy", pts)
+    np.savetxt(tmp_path / "maps" / "base_map.asc", pts)
+    monkeypatch.setenv("DATA", str(tmp_path))
+    for name in ("base_map.asc.npy", "base_map.asc"):
+        got = util.load_point_cloud_map({"TRAIN": {"MAP": name}})
+        assert got.dtype == torch.float32 and got.shape == (50, 3)
+        np.testing.assert_array_equal(got.numpy(), (pts if name.endswith(".npy") else pts.astype(np.float32))[:, :3].astype(np.float32))
+    with pytest.raises(AssertionError, match="cfg is None"):
+        util.load_point_cloud_map(None)
+    with pytest.raises(RuntimeError, match="Failed to load point cloud map"):
+        util.load_point_cloud_map({"TRAIN": {"MAP": "missing.npy"}})
