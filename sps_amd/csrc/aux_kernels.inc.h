@@ -12,7 +12,7 @@ struct MetricsArgs {
   double *acc;         // [n_batches][8], zero before the kernel; null = no metrics (k_tail only)
 };
 
-// Workgroup `bid` of `nb`: per-batch-index accumulation over the scan rows it visits (grid-stride over n points).
+// Workgroup `bid` of `nb`: per-batch-index accumulation over the scan rows of its contiguous segment of the n points.
 // SLICE = true also produces the scores (slice + sigmoid, models.py:28-29) it then scores against the labels -- the
 // fused tail of sps_forward_metrics; SLICE = false reads them from `scores` (sps_metrics*).
 // Few workgroups, each thread accumulates its rows in registers; a thread flushes early only when the batch index of
@@ -24,7 +24,13 @@ __device__ inline void metrics_body(float *__restrict__ scores, const float *__r
   __shared__ int bsh[4];
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   int b = -1;
-  for (int p = bid * (int)blockDim.x + (int)threadIdx.x; p < n; p += nb * (int)blockDim.x) {
+  // every workgroup owns ONE contiguous segment of the rows (rows are grouped by batch index, collate_fn): a batch
+  // boundary then falls into a single workgroup, whose threads flush once; with a grid-strided assignment every thread
+  // of every workgroup crossed every boundary and the per-thread flushes (8 atomics each) serialised on 8 n_batches
+  // addresses -- 4.7 ms per step at batch = 4
+  const int seg = (((n + nb - 1) / nb) + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x;
+  const int p_end = min(n, (bid + 1) * seg);
+  for (int p = bid * seg + (int)threadIdx.x; p < p_end; p += (int)blockDim.x) {
     float s;
     if (SLICE) {
       const int vr = inv[p];

@@ -92,7 +92,6 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_W4
 #define SPS_W4 4
 #endif
-
 #include "keys_hash.inc.h"
 #include "grid_kernels.inc.h"
 #include "map_kernels.inc.h"
@@ -424,17 +423,19 @@ struct Geometry {
   int ntw, S;
 };
 Geometry conv_geometry(int level, int K, int cin, int nt) {
-  if (K == 8 && level >= 3) return {1, 4};  // stride convs into the two coarsest levels: ~100-300 tiles, split four ways
+  if (K == 8 && level >= 3) return {std::min(2, nt), 4};  // stride convs into the two coarsest levels: ~100-300 tiles, split four ways
   if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
   (void)cin;
   // levels 0-1: thousands of tiles, one wave per tile and all its column tiles.  Levels 2-4: few tiles, each wave a
-  // chain of dependent load -> MFMA rounds: one column tile per wave and four splits per tile (one workgroup, LDS
-  // reduction) shorten the chain; serial 0.552 -> 0.506 ms, pipelined throughput unchanged
-  Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{1, 4};
-  // tuning hook (diagnostics): SPS_GEOM_L<level>="<full>,<S>"  full=1 -> one wave owns all column tiles; read once
+  // chain of dependent load -> MFMA rounds: four splits per tile (one workgroup, LDS reduction) shorten the chain
+  // (serial 0.552 -> 0.506 ms) and two column tiles per wave halve the re-gathers of A (pipelined +2.7 % per level
+  // group over one column tile per wave, tools/geom_sweep.sh)
+  Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{std::min(2, nt), 4};
+  // tuning hook (diagnostics): SPS_GEOM_L<level>="<ntw>,<S>"  column tiles per wave (1, 2, 4; clipped to NT) and splits
+  // of the unit list inside the workgroup (1, 2, 4); read once
   struct Hook {
     bool set = false;
-    int full = 0, S = 1;
+    int ntw = 1, S = 1;
   };
   static const std::array<Hook, SPS_NUM_LEVELS> hooks = [] {
     std::array<Hook, SPS_NUM_LEVELS> h{};
@@ -442,12 +443,13 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
       char name[32];
       snprintf(name, sizeof name, "SPS_GEOM_L%d", l);
       const char *e = getenv(name);
-      int full = 0, S = 1;
-      if (e && sscanf(e, "%d,%d", &full, &S) == 2 && (S == 1 || S == 2 || S == 4)) h[l] = Hook{true, full, S};
+      int ntw = 1, S = 1;
+      if (e && sscanf(e, "%d,%d", &ntw, &S) == 2 && (S == 1 || S == 2 || S == 4) && (ntw == 1 || ntw == 2 || ntw == 4))
+        h[l] = Hook{true, ntw, S};
     }
     return h;
   }();
-  if (level >= 0 && level < SPS_NUM_LEVELS && hooks[level].set) g = {hooks[level].full ? nt : 1, hooks[level].S};
+  if (level >= 0 && level < SPS_NUM_LEVELS && hooks[level].set) g = {std::min(hooks[level].ntw, nt), hooks[level].S};
   return g;
 }
 
@@ -543,35 +545,31 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   }
   const bool ds = cs.ds_cin > 0;
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
-  if (g.S > 1 && g.ntw != 1) return fail(SPS_ERR_INVALID, "split-K needs one column tile per wave");
-  if (g.S == 4) {
-    if (ds)
-      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_WS, true, false, 4>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_WS, false, false, 4>), grid, dim3(256), 0, st, a);
-  } else if (g.S == 2) {
-    if (ds)
-      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_WS, true, false, 2>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_WS, false, false, 2>), grid, dim3(256), 0, st, a);
-  } else if (g.ntw == 1) {
-    if (cc.fin)
-      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
-    else if (ds)
-      hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, false, 1>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_W1, false, false, 1>), grid, dim3(256), 0, st, a);
-  } else if (g.ntw == 2) {
-    if (ds)
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, true, false, 1>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, SPS_W2, false, false, 1>), grid, dim3(256), 0, st, a);
-  } else {
-    if (ds)
-      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, true, false, 1>), grid, dim3(256), 0, st, a);
-    else
-      hipLaunchKernelGGL((k_conv<4, SPS_G4, SPS_W4, false, false, 1>), grid, dim3(256), 0, st, a);
+  if (cc.fin) {
+    hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
+    return SPS_OK;
   }
+#define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
+  do {                                                                                            \
+    if (ds)                                                                                       \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(256), 0, st, a);     \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(256), 0, st, a);    \
+  } while (0)
+  const int key = g.ntw * 10 + g.S;
+  switch (key) {
+    case 11: SPS_LAUNCH(1, SPS_G1, SPS_W1, 1); break;
+    case 12: SPS_LAUNCH(1, SPS_G1, SPS_WS, 2); break;
+    case 14: SPS_LAUNCH(1, SPS_G1, SPS_WS, 4); break;
+    case 21: SPS_LAUNCH(2, SPS_G2, SPS_W2, 1); break;
+    case 22: SPS_LAUNCH(2, SPS_G2, SPS_W2, 2); break;
+    case 24: SPS_LAUNCH(2, SPS_G2, SPS_W2, 4); break;
+    case 41: SPS_LAUNCH(4, SPS_G4, SPS_W4, 1); break;
+    case 42: SPS_LAUNCH(4, SPS_G4, SPS_W4, 2); break;
+    case 44: SPS_LAUNCH(4, SPS_G4, SPS_W4, 4); break;
+    default: return fail(SPS_ERR_INVALID, "unsupported conv geometry ntw = %d, S = %d", g.ntw, g.S);
+  }
+#undef SPS_LAUNCH
   return SPS_OK;
 }
 

@@ -88,6 +88,74 @@ __global__ __launch_bounds__(256) void k_replay_lds(const unsigned short *__rest
   if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = acc.x;
 }
 
+// MODE 4: quad-coherent global -> LDS DMA (buffer_load_dwordx4 ... lds, no VGPRs) + ds_read_b128 in the MFMA A layout.
+// Lane l fetches chunk (l & 3) of the group's units for row-slot l >> 2, so the four lanes of a quad read one row's
+// consecutive 16-byte chunks (one 64-byte segment when C >= 16); the DMA writes lane l's 16 bytes at stage + 16 l, i.e.
+// [16 rows][4 units][16 B]; the MFMA operand of lane (r, q) is then the 16 bytes at (4 r + q) * 16: conflict-free.
+template <int DEPTH>
+__global__ __launch_bounds__(256, 8) void k_replay_dma(const int *__restrict__ nbr, const uint32_t *__restrict__ tmask, int V, int64_t ldn,
+                                                       const char *__restrict__ feat, uint32_t feat_bytes, int C, double *out) {
+  __shared__ uint32_t rows_s[4][81 * 16];
+  __shared__ unsigned char kl_s[4][128];
+  __shared__ __attribute__((aligned(16))) char stage_s[4][DEPTH][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int rr = lane >> 2, s4 = lane & 3;
+  const int ntiles = (V + 15) >> 4;
+  uint32_t *rs = rows_s[wave];
+  unsigned char *kl = kl_s[wave];
+  const __amdgpu_buffer_rsrc_t rsF = __builtin_amdgcn_make_buffer_rsrc((void *)feat, 0, (int)feat_bytes, 0x00020000);
+  float4 acc = {0, 0, 0, 0};
+  const int upk = C / 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row0 = tile * 16;
+    const uint32_t *m = tmask + (size_t)tile * 4;
+    const uint32_t w0 = m[lane >> 5], w1 = m[2 + (lane >> 5)];
+    const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = lane + 64 < 81 && ((w1 >> (lane & 31)) & 1u);
+    const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int n0 = __popcll(bal0);
+    __builtin_amdgcn_wave_barrier();
+    if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)lane;
+    if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(lane + 64);
+    const int nk = n0 + __popcll(bal1);
+    __builtin_amdgcn_wave_barrier();
+    for (int j = 0; j < nk; j += 4) {
+      const int jj = j + q;
+      if (jj < nk) {
+        const int k = kl[jj];
+        const int u = row0 + r;
+        const int v = u < V ? nbr[(size_t)k * ldn + u] : -1;
+        rs[jj * 16 + r] = v < 0 ? 0xFFFFFFFFu : (uint32_t)v * (uint32_t)(C * 4);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int U = nk * upk;
+    for (int i = 0; i < U; i += 4 * DEPTH) {
+#pragma unroll
+      for (int e = 0; e < DEPTH; ++e) {
+        const int unit = i + 4 * e + s4;
+        const int j = unit / upk, c4 = unit - j * upk;
+        uint32_t off = rs[min(j, nk - 1) * 16 + rr];
+        off = unit < U ? off : 0xFFFFFFFFu;
+        off = __builtin_elementwise_add_sat(off, (uint32_t)c4 * 16u);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsF, (__attribute__((address_space(3))) void *)&stage_s[wave][e][0], 16, off, 0, 0, 0);
+      }
+      __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int e = 0; e < DEPTH; ++e) {
+        const float4 v = *reinterpret_cast<const float4 *>(&stage_s[wave][e][(4 * r + q) * 16]);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  double t = (double)acc.x + acc.y + acc.z + acc.w;
+  for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+  if (lane == 0) out[blockIdx.x * 4 + wave] = t;   // per-wave partial (one atomic address would serialise)
+}
+
 template <int MODE>  // 0 stage only, 1 row-major, 2 planar
 __global__ __launch_bounds__(256, 8) void k_replay(const int *__restrict__ nbr, const uint32_t *__restrict__ tmask, int V, int64_t ldn,
                                                    const char *__restrict__ feat, uint32_t feat_bytes, uint32_t plane_bytes, int C,
@@ -227,7 +295,34 @@ int main(int argc, char **argv) {
       CHECK(hipEventSynchronize(b));
       CHECK(hipEventElapsedTime(&ms3, a, b));
     }
-    printf("C = %2d: stage only %.1f us, row-major %.1f us, planar %.1f us, LDS cache %.1f us\n", C, ms[0] * 1e3, ms[1] * 1e3, ms[2] * 1e3, ms3 * 1e3);
+    // MODE 4: DMA to LDS.  Features = 1.0 so that the sum of everything read must be pairs * C (out-of-range lanes must
+    // deliver zeros INTO LDS, not leave stale data)
+    {
+      std::vector<float> ones((size_t)ldn * C, 1.0f);
+      CHECK(hipMemcpy(feat, ones.data(), fbytes, hipMemcpyHostToDevice));
+    }
+    double *dsum;
+    std::vector<double> hsum((size_t)grid * 4);
+    CHECK(hipMalloc(&dsum, hsum.size() * 8));
+    float ms4[2] = {0, 0};
+    double sums[2] = {0, 0};
+    for (int depth = 0; depth < 2; ++depth)
+      for (int rep = 0; rep < 3; ++rep) {
+        CHECK(hipMemset(dsum, 0, hsum.size() * 8));
+        CHECK(hipEventRecord(a));
+        if (depth == 0) hipLaunchKernelGGL((k_replay_dma<2>), dim3(grid), dim3(256), 0, 0, dn, dm, (int)V, ldn, feat, (uint32_t)fbytes, C, dsum);
+        else hipLaunchKernelGGL((k_replay_dma<4>), dim3(grid), dim3(256), 0, 0, dn, dm, (int)V, ldn, feat, (uint32_t)fbytes, C, dsum);
+        CHECK(hipEventRecord(b));
+        CHECK(hipEventSynchronize(b));
+        CHECK(hipEventElapsedTime(&ms4[depth], a, b));
+        CHECK(hipMemcpy(hsum.data(), dsum, hsum.size() * 8, hipMemcpyDeviceToHost));
+        sums[depth] = 0;
+        for (double x : hsum) sums[depth] += x;
+      }
+    long long pairs = 0;
+    for (int k = 0; k < 81; ++k) for (int64_t u = 0; u < V; ++u) pairs += nbr[(size_t)k * ldn + u] >= 0;
+    printf("C = %2d: stage only %.1f us, row-major %.1f us, planar %.1f us, LDS cache %.1f us, DMA->LDS depth2 %.1f us depth4 %.1f us (sum %.0f / %.0f, want %lld)\n",
+           C, ms[0] * 1e3, ms[1] * 1e3, ms[2] * 1e3, ms3 * 1e3, ms4[0] * 1e3, ms4[1] * 1e3, sums[0], sums[1], pairs * C);
     CHECK(hipFree(feat));
   }
   return 0;
