@@ -88,6 +88,18 @@ def calibrate_final(net, batch, eps, frac=0.3, gain=8.0):
     return float(sd[KEY_B].reshape(-1)[0])
 
 
+def morton_sorted(batch, vs):
+    """Rows of a [N,6] batch sorted by (batch index, Z-order of the 0.4 m block of the voxel, time index)."""
+    q = np.floor(batch[:, 1:4] / np.float32(vs)).astype(np.int64) + (1 << 17)
+    blk = q >> 2
+    key = np.zeros(len(batch), np.int64)
+    for bit in range(16):
+        for ax in range(3):
+            key |= ((blk[:, ax] >> bit) & 1) << (3 * bit + ax)
+    key = (batch[:, 0].astype(np.int64) << 56) | (key << 1) | batch[:, 4].astype(np.int64)
+    return np.ascontiguousarray(batch[np.argsort(key, kind="stable")])
+
+
 def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sps_amd", "csrc")
@@ -135,6 +147,10 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the second (host-buffer-fed) timed region")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-layer hipEvent pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--order", default="scan", choices=["scan", "morton"],
+                    help="DIAGNOSTIC: row order of the synthetic batches -- 'scan' = as a LiDAR delivers them (ring by ring; "
+                         "the default and the headline), 'morton' = rows pre-sorted by the Z-order of their voxel (probes how "
+                         "much the voxel-row order, which follows the first occurrence of each block, costs in cache locality)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +184,9 @@ def main():
 
     # ---- workload (host generation is not timed) ----------------------------------------------------------------
     batches_np, nb, workload = build_workload(args.config, rank, args.azimuth, args.seq_scans, vs)
+    if args.order == "morton":
+        batches_np = [morton_sorted(b, vs) for b in batches_np]
+        workload += " [rows pre-sorted in Morton order: diagnostic]"
     batches = [torch.from_numpy(b).to(dev) for b in batches_np]
     pinned = [torch.from_numpy(b).pin_memory() for b in batches_np]
     max_rows = max(len(b) for b in batches_np)

@@ -211,6 +211,24 @@ int sps_radius_count(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64
 int sps_radius_fill(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64_t n, const int64_t *offsets_dev,
                     int64_t *out_idx_dev, void *stream);
 
+/* ---- training step ---------------------------------------------------------
+ * Replaces the forward + loss.backward() of SPSNet.training_step / common_step (reference
+ * src/sps/models/models.py:62-82) for the network part; the loss (nn.MSELoss on the scan rows) and the optimiser
+ * (Adam + StepLR, models.py:154-160) stay with the caller.
+ * sps_train_forward: params_dev is the flat parameter blob ON THE DEVICE in the layout of sps_weights_tensor_info
+ *   (kernels [K][C_in][C_out], BN weight / bias / running_mean / running_var, final.bias); the running statistics are
+ *   ignored: BatchNorm normalises with the batch statistics of the active rows (train mode, eps = 1e-5) and
+ *   batch_stats_dev (optional, [2 * sum of BN widths] floats: per conv in layer order the batch mean then the BIASED
+ *   batch variance of its BN) lets the caller update running_mean / running_var as nn.BatchNorm1d does.  scores_dev [n]
+ *   = sigmoid(final(...)) sliced to the points, as sps_forward.  The activations the backward needs stay in ctx.
+ * sps_train_backward: dscores_dev [n] = d(loss)/d(scores); scores_dev the forward's output; grad_dev receives
+ *   d(loss)/d(parameter) in the blob layout (zeros in the running-statistics slots).  Deterministic (fixed-order
+ *   reductions).  Stream-ordered, no host synchronisation. */
+int sps_train_forward(sps_ctx *ctx, const float *params_dev, int64_t numel, const float *coords_dev, int64_t ld, int64_t n,
+                      float voxel_size, float *scores_dev, float *batch_stats_dev, void *stream);
+int sps_train_backward(sps_ctx *ctx, const float *dscores_dev, const float *scores_dev, float *grad_dev, int64_t numel,
+                       void *stream);
+
 /* ---- per-stage timing (hipEvents on the caller's stream; for bench.py / DESIGN.md) ------
  * With profiling on, sps_forward records one event after every stage ("reset", "voxelize",
  * "pyramid", "maps", one per convolution by state_dict name, "slice_sigmoid").  After a forward,

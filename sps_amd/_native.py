@@ -71,6 +71,8 @@ def _load() -> C.CDLL:
         "sps_filter_prepare": (i32, [vp, vp, i32, i64, i64, vp, vp, vp, vp]),
         "sps_forward_n": (i32, [vp, vp, i64, i64, vp, f32, vp, vp]),
         "sps_compact_stable": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),
+        "sps_train_forward": (i32, [vp, vp, i64, vp, i64, i64, f32, vp, vp, vp]),
+        "sps_train_backward": (i32, [vp, vp, vp, vp, i64, vp]),
         "sps_radius_grid_upload": (i32, [vp, vp, vp, vp, vp, i64, i64, C.c_double, C.c_double, vp]),
         "sps_radius_count": (i32, [vp, vp, i64, i64, vp, vp]),
         "sps_radius_fill": (i32, [vp, vp, i64, i64, vp, vp, vp]),
@@ -102,7 +104,7 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_transform_points", "sps_filter_prepare", "sps_forward_n",
-           "sps_compact_stable", "sps_radius_grid_upload", "sps_radius_count",
+           "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_radius_grid_upload", "sps_radius_count",
            "sps_radius_fill", "sps_level_counts", "sps_get_voxels",
            "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_logits", "sps_get_feature"]
 
@@ -257,6 +259,14 @@ class Context:
     def compact_stable(self, scores_ptr: int, rows_ptr: int, ld: int, cols: int, n: int, eps: float, out_ptr: int,
                        count_ptr: int, stream: int):
         check(lib.sps_compact_stable(self.handle, scores_ptr, rows_ptr, ld, cols, n, eps, out_ptr, count_ptr, stream))
+
+    def train_forward(self, params_ptr: int, numel: int, coords_ptr: int, ld: int, n: int, voxel_size: float,
+                      scores_ptr: int, batch_stats_ptr, stream: int):
+        check(lib.sps_train_forward(self.handle, params_ptr, numel, coords_ptr, ld, n, voxel_size, scores_ptr,
+                                    batch_stats_ptr, stream))
+
+    def train_backward(self, dscores_ptr: int, scores_ptr: int, grad_ptr: int, numel: int, stream: int):
+        check(lib.sps_train_backward(self.handle, dscores_ptr, scores_ptr, grad_ptr, numel, stream))
 
     def level_counts(self):
         out = (C.c_int64 * NUM_LEVELS)()

@@ -381,8 +381,8 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
   const int r = lane & 15, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
-  const int upk = a.upk;            // 4, 8 or 16 units (C_in = 16, 32, 64)
-  const int ngrp = upk >> 2;        // unit groups of 4 (one per lane group q)
+  const int upk = a.upk;            // 2, 4, 8 or 16 units (C_in = 8 [training: data gradients], 16, 32, 64)
+  const int ngrp = (upk + 3) >> 2;  // unit groups of 4 (one per lane group q)
   float esc[NT], esh[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
     u32x4 va[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const uint32_t oa = (i < ngrp && row < count) ? (uint32_t)row * ((uint32_t)a.ldi * 4u) + (uint32_t)(4 * i + q) * 16u : OOR;
+      const uint32_t oa = (i < ngrp && 4 * i + q < upk && row < count) ? (uint32_t)row * ((uint32_t)a.ldi * 4u) + (uint32_t)(4 * i + q) * 16u : OOR;
       va[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
     }
 #pragma unroll
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (i >= ngrp) break;
-        const uint32_t ob = ((uint32_t)(k * upk + 4 * i + q) * (uint32_t)NT) * 256u + (uint32_t)r * 16u;
+        const uint32_t ob = 4 * i + q < upk ? ((uint32_t)(k * upk + 4 * i + q) * (uint32_t)NT) * 256u + (uint32_t)r * 16u : OOR;
         u32x4 vb[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) vb[nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
@@ -437,6 +437,7 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
         for (int i = 0; i < 4; ++i) {
           if (child[i] < 0) continue;
           float y = acc[nt][i] * esc[nt] + esh[nt];
+          if (a.res) y += a.res[(size_t)child[i] * a.ldr + col];  // accumulate (training: data gradient of a stride conv)
           if (a.relu) y = fmaxf(y, 0.f);
           a.out[(size_t)child[i] * a.ldo + col] = y;
         }
@@ -456,7 +457,7 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
 __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_out, LevelView L,
                                                       const float *__restrict__ W, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, float in_const,
-                                                      float *__restrict__ out, int ldo) {
+                                                      float *__restrict__ out, int ldo, int relu) {
   __shared__ float w_s[128 * 8];
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
@@ -530,7 +531,10 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int ro = row0 + q * 4 + i;
-        if (ro < n) out[(size_t)ro * ldo + r] = fmaxf(acc[i] * esc + esh, 0.f);
+        if (ro < n) {
+          const float y = acc[i] * esc + esh;
+          out[(size_t)ro * ldo + r] = relu ? fmaxf(y, 0.f) : y;  // relu = 0: raw output for train-mode BatchNorm
+        }
       }
     }
   }

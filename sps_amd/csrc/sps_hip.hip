@@ -98,6 +98,7 @@ int fail(int code, const char *fmt, ...) {
 #include "conv_kernels.inc.h"
 #include "aux_kernels.inc.h"
 #include "netspec.inc.h"
+#include "train_kernels.inc.h"
 
 // ------------------------------------------------------------------------------------------
 // context
@@ -167,8 +168,11 @@ struct sps_weights_handle {  // what the C ABI hands out: one reference
   std::shared_ptr<sps_weights> w;
 };
 
+struct sps_train;  // training arena + saved activations (train_host.inc.h)
+
 struct sps_ctx {
   int device = 0;
+  sps_train *train = nullptr;
   int64_t cap = 0;       // arena capacity in rows (points)
   int64_t hcap = 0;      // hash capacity
   int64_t last_n = 0;    // points of the last forward
@@ -520,7 +524,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       return SPS_OK;
     }
     hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
-                       c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo);
+                       c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo, 1);
     return SPS_OK;
   }
   if (cs.K == 8 && std::strncmp(cc.name, "convtr", 6) == 0) {
@@ -658,10 +662,13 @@ int sps_ctx_create(int device, sps_ctx **out) {
   return SPS_OK;
 }
 
+static void train_destroy(sps_ctx *c);
+
 int sps_ctx_destroy(sps_ctx *c) {
   if (!c) return SPS_OK;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
+  train_destroy(c);
   free_arena(c);
   (void)hipFree(c->err);
   (void)hipFree(c->macc);
@@ -843,6 +850,8 @@ struct ForwardOpts {
   int n_batches = 0;
   // sps_forward_n: the row count lives on the device (written by an earlier kernel of the stream); n is its bound
   const int *n_dev = nullptr;
+  // sps_train_forward: coordinate structures and kernel maps only (the train-mode network follows)
+  bool front_only = false;
 };
 
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
@@ -1014,6 +1023,10 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   c->diag_have_state = true;
   }  // !skip_front
   prof_mark(c, "maps", st);
+  if (fo.front_only) {
+    HIP_TRY(hipGetLastError());
+    return SPS_OK;  // the caller runs its own network and the hash clean-up
+  }
   // ---- network (minkunet.py:161-219)
   Level *lv = c->lv;
   c->cur_vfeat = fo.feats ? c->vfeat : nullptr;
@@ -1080,6 +1093,15 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   HIP_TRY(hipGetLastError());
   c->tables_dirty = false;
   return SPS_OK;
+}
+
+#include "train_host.inc.h"
+
+static void train_destroy(sps_ctx *c) {
+  if (!c->train) return;
+  train_free(c->train);
+  delete c->train;
+  c->train = nullptr;
 }
 
 int sps_profile_enable(sps_ctx *c, int on) {

@@ -1,0 +1,477 @@
+// train_host.inc.h -- part of sps_hip.hip (included inside its extern "C" block): orchestration of one training step
+// of the SPS network on the context's device (reference src/sps/models/models.py:62-82 + :154-160).
+//
+//   sps_train_forward : quantise / voxelise / maps exactly as sps_forward, then CustomMinkUNet14 in TRAIN mode -- every
+//                       conv writes its raw output z, BatchNorm uses the batch statistics of the active rows, the block
+//                       wiring (residual, 1x1 downsample branch, concat) is that of minkunet.py:161-219 -- slice, sigmoid.
+//                       Saves what the backward needs inside the context.
+//   sps_train_backward: d(loss)/d(scores) in, gradient of every parameter out (flat blob in the layout of
+//                       sps_weights_tensor_info).  Data gradients reuse the forward's gather kernels over the same
+//                       kernel maps with mirrored / transposed weights; weight gradients are MFMA reductions over the
+//                       map's pairs (k_wgrad); BN / ReLU / residual backward in k_bn_bwd_*.
+// The loss (nn.MSELoss on the scan rows, models.py:62-70) and the optimiser (Adam + StepLR, models.py:154-160) stay in
+// torch: they are a handful of elementwise kernels on tensors torch already owns.
+
+extern "C++" {
+namespace {
+
+struct TView {      // a feature tensor view: `cols` columns starting at column 0 of (ptr, ld); g = its gradient
+  float *p = nullptr, *g = nullptr;
+  int ld = 0, cols = 0, level = 0;
+};
+
+enum TKind { T_CONV0 = 0, T_K3 = 1, T_DOWN = 2, T_UP = 3, T_LIN = 4 };
+
+struct TOp {
+  const char *name;  // conv name in the spec (its BN follows)
+  TKind kind;
+  TView in, out;     // out = destination of relu?(bn(z) [+ res])
+  int relu;
+  TView res;         // residual operand (p == nullptr: none)
+};
+
+}  // namespace
+
+struct sps_train {
+  int64_t cap = 0;
+  const NetSpec *net = nullptr;
+  std::vector<void *> allocs;
+  float *blob = nullptr, *grad = nullptr;  // parameters / gradients, flat [numel]
+  float *wu = nullptr, *wut = nullptr;     // forward / data-gradient MFMA operands
+  std::vector<int64_t> wu_off, wut_off;    // per conv (floats)
+  std::vector<float *> z;                  // per conv: raw output [cap, cout]
+  float *gpool = nullptr;                  // gradients of the feature buffers (one allocation, zeroed per backward)
+  size_t gpool_bytes = 0;
+  float *r_p[9] = {}, *r_g[9] = {};        // BN'd 1x1 downsample branch (the residual operand) of block i (2..8)
+  float *dz = nullptr;                     // scratch: gradient wrt a raw conv output [cap, 64]
+  float *slab = nullptr;
+  size_t slab_floats = 0;
+  double *bn_part = nullptr, *bn_bpart = nullptr, *fin_part = nullptr;
+  float *batch_stats = nullptr;            // per BN [2][C] at 2 * ss_off-like offsets (same as c->ss layout)
+  float *ones = nullptr, *zeros = nullptr;
+  float *c0part = nullptr;
+  long long *vacc = nullptr;
+  // gradient views of the context's feature buffers, in the order of feat_list()
+  std::vector<TView> views;
+  int64_t n_last = 0;
+  bool have_forward = false;
+};
+
+namespace {
+
+void train_free(sps_train *t) {
+  for (void *p : t->allocs) (void)hipFree(p);
+  t->allocs.clear();
+  t->cap = 0;
+  t->have_forward = false;
+}
+
+#define TALLOC(ptr, type, count)                                                                    \
+  do {                                                                                              \
+    void *p_ = nullptr;                                                                             \
+    hipError_t e_ = hipMalloc(&p_, sizeof(type) * (size_t)((count) > 0 ? (count) : 4));             \
+    if (e_ != hipSuccess) return fail(SPS_ERR_NOMEM, "hipMalloc (training arena) failed: %s", hipGetErrorString(e_)); \
+    t->allocs.push_back(p_);                                                                        \
+    ptr = reinterpret_cast<type *>(p_);                                                             \
+  } while (0)
+
+// the context's feature buffers (name, pointer, row stride, level) -- gradients get the same shapes
+struct FeatDesc {
+  float *p;
+  int ld, level;
+};
+std::vector<FeatDesc> feat_list(sps_ctx *c) {
+  return {{c->cat8, 16, 0}, {c->b8t, 8, 0}, {c->b8o, 8, 0}, {c->x1, 8, 1},  {c->b1t, 8, 1},  {c->cat7, 24, 1}, {c->b7t, 16, 1},
+          {c->b7o, 16, 1},  {c->x2, 8, 2},  {c->b2t, 16, 2}, {c->cat6, 48, 2}, {c->b6t, 32, 2}, {c->b6o, 32, 2}, {c->x3, 16, 3},
+          {c->b3t, 32, 3},  {c->cat5, 96, 3}, {c->b5t, 64, 3}, {c->b5o, 64, 3}, {c->x4, 32, 4}, {c->b4t, 64, 4}, {c->b4o, 64, 4}};
+}
+
+int train_reserve(sps_ctx *c) {
+  if (!c->train) c->train = new sps_train();
+  sps_train *t = c->train;
+  if (t->cap == c->cap && t->net == c->net && t->cap > 0) return SPS_OK;
+  HIP_TRY(hipDeviceSynchronize());
+  train_free(t);
+  const NetSpec &s = *c->net;
+  const int64_t cap = c->cap;
+  t->net = &s;
+  TALLOC(t->blob, float, s.numel);
+  TALLOC(t->grad, float, s.numel);
+  // MFMA operands: forward (C_in x C_out) and data gradient (C_out x C_in) per conv
+  t->wu_off.assign(s.convs.size(), 0);
+  t->wut_off.assign(s.convs.size(), 0);
+  int64_t nwu = 0, nwut = 0;
+  for (size_t i = 0; i < s.convs.size(); ++i) {
+    const ConvSpec &cs = s.convs[i];
+    t->wu_off[i] = nwu;
+    t->wut_off[i] = nwut;
+    if (cs.cin == 1 || cs.name == "final") continue;
+    nwu += (int64_t)cs.K * (cs.cin / 4) * ((cs.cout + 15) / 16) * 64;
+    nwut += (int64_t)cs.K * (cs.cout / 4) * ((cs.cin + 15) / 16) * 64;
+  }
+  TALLOC(t->wu, float, nwu);
+  TALLOC(t->wut, float, nwut);
+  t->z.assign(s.convs.size(), nullptr);
+  for (size_t i = 0; i < s.convs.size(); ++i) {
+    if (s.convs[i].name == "final") continue;
+    TALLOC(t->z[i], float, (size_t)cap * s.convs[i].cout);
+  }
+  // gradients of the feature buffers + of the residual operands, one pool
+  const auto feats = feat_list(c);
+  size_t gfloats = 0;
+  for (const FeatDesc &f : feats) gfloats += (size_t)cap * f.ld;
+  const int rcols[9] = {0, 0, 16, 32, 64, 64, 32, 16, 8};  // C_out of block i's downsample branch (block1 has none)
+  size_t rfloats = 0;
+  for (int b = 2; b <= 8; ++b) rfloats += (size_t)cap * rcols[b];
+  TALLOC(t->gpool, float, gfloats + rfloats);
+  t->gpool_bytes = (gfloats + rfloats) * sizeof(float);
+  t->views.clear();
+  float *gp = t->gpool;
+  for (const FeatDesc &f : feats) {
+    TView v;
+    v.p = f.p;
+    v.g = gp;
+    v.ld = f.ld;
+    v.cols = f.ld;
+    v.level = f.level;
+    t->views.push_back(v);
+    gp += (size_t)cap * f.ld;
+  }
+  for (int b = 2; b <= 8; ++b) {
+    t->r_g[b] = gp;
+    gp += (size_t)cap * rcols[b];
+    TALLOC(t->r_p[b], float, (size_t)cap * rcols[b]);
+  }
+  TALLOC(t->dz, float, (size_t)cap * 64);
+  t->slab_floats = (size_t)81 * 24 * 16 * 256;  // K * (MT * NT <= 24) * nchunk (<= 16) tiles of 16 x 16
+  TALLOC(t->slab, float, t->slab_floats);
+  TALLOC(t->bn_part, double, (size_t)s.bns.size() * BN_WG * 2 * BN_MAXC);
+  TALLOC(t->bn_bpart, double, (size_t)BN_WG * 2 * BN_MAXC);
+  TALLOC(t->fin_part, double, (size_t)BN_WG * 9);
+  TALLOC(t->batch_stats, float, s.ss_numel);
+  TALLOC(t->ones, float, 128);
+  TALLOC(t->zeros, float, 128);
+  TALLOC(t->c0part, float, (size_t)256 * 1000);
+  TALLOC(t->vacc, long long, cap);
+  std::vector<float> one(128, 1.f);
+  HIP_TRY(hipMemcpy(t->ones, one.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemset(t->zeros, 0, 128 * sizeof(float)));
+  HIP_TRY(hipMemset(t->batch_stats, 0, s.ss_numel * sizeof(float)));
+  t->cap = cap;
+  return SPS_OK;
+}
+
+TView view_of(sps_train *t, const float *p) {
+  for (const TView &v : t->views)
+    if (v.p == p) return v;
+  return TView{};
+}
+TView cols_of(TView v, int col0, int cols) {  // sub-view: columns [col0, col0 + cols)
+  v.p += col0;
+  v.g += col0;
+  v.cols = cols;
+  return v;
+}
+
+// the network as a list of conv + BN (+ residual) (+ ReLU) ops in forward order (minkunet.py:161-219, resnet BasicBlock)
+std::vector<TOp> train_ops(sps_ctx *c) {
+  sps_train *t = c->train;
+  auto V = [&](const float *p) { return view_of(t, p); };
+  auto R = [&](int block, int level, int cols) {
+    TView v;
+    v.p = t->r_p[block];
+    v.g = t->r_g[block];
+    v.ld = cols;
+    v.cols = cols;
+    v.level = level;
+    return v;
+  };
+  const TView none{};
+  const TView cat8 = V(c->cat8), cat7 = V(c->cat7), cat6 = V(c->cat6), cat5 = V(c->cat5);
+  std::vector<TOp> ops;
+  ops.push_back({"conv0p1s1", T_CONV0, none, cols_of(cat8, 8, 8), 1, none});
+  ops.push_back({"conv1p1s2", T_DOWN, cols_of(cat8, 8, 8), V(c->x1), 1, none});
+  ops.push_back({"block1.0.conv1", T_K3, V(c->x1), V(c->b1t), 1, none});
+  ops.push_back({"block1.0.conv2", T_K3, V(c->b1t), cols_of(cat7, 16, 8), 1, V(c->x1)});
+  ops.push_back({"conv2p2s2", T_DOWN, cols_of(cat7, 16, 8), V(c->x2), 1, none});
+  ops.push_back({"block2.0.conv1", T_K3, V(c->x2), V(c->b2t), 1, none});
+  ops.push_back({"block2.0.downsample.0", T_LIN, V(c->x2), R(2, 2, 16), 0, none});
+  ops.push_back({"block2.0.conv2", T_K3, V(c->b2t), cols_of(cat6, 32, 16), 1, R(2, 2, 16)});
+  ops.push_back({"conv3p4s2", T_DOWN, cols_of(cat6, 32, 16), V(c->x3), 1, none});
+  ops.push_back({"block3.0.conv1", T_K3, V(c->x3), V(c->b3t), 1, none});
+  ops.push_back({"block3.0.downsample.0", T_LIN, V(c->x3), R(3, 3, 32), 0, none});
+  ops.push_back({"block3.0.conv2", T_K3, V(c->b3t), cols_of(cat5, 64, 32), 1, R(3, 3, 32)});
+  ops.push_back({"conv4p8s2", T_DOWN, cols_of(cat5, 64, 32), V(c->x4), 1, none});
+  ops.push_back({"block4.0.conv1", T_K3, V(c->x4), V(c->b4t), 1, none});
+  ops.push_back({"block4.0.downsample.0", T_LIN, V(c->x4), R(4, 4, 64), 0, none});
+  ops.push_back({"block4.0.conv2", T_K3, V(c->b4t), V(c->b4o), 1, R(4, 4, 64)});
+  ops.push_back({"convtr4p16s2", T_UP, V(c->b4o), cols_of(cat5, 0, 64), 1, none});
+  ops.push_back({"block5.0.conv1", T_K3, cat5, V(c->b5t), 1, none});
+  ops.push_back({"block5.0.downsample.0", T_LIN, cat5, R(5, 3, 64), 0, none});
+  ops.push_back({"block5.0.conv2", T_K3, V(c->b5t), V(c->b5o), 1, R(5, 3, 64)});
+  ops.push_back({"convtr5p8s2", T_UP, V(c->b5o), cols_of(cat6, 0, 32), 1, none});
+  ops.push_back({"block6.0.conv1", T_K3, cat6, V(c->b6t), 1, none});
+  ops.push_back({"block6.0.downsample.0", T_LIN, cat6, R(6, 2, 32), 0, none});
+  ops.push_back({"block6.0.conv2", T_K3, V(c->b6t), V(c->b6o), 1, R(6, 2, 32)});
+  ops.push_back({"convtr6p4s2", T_UP, V(c->b6o), cols_of(cat7, 0, 16), 1, none});
+  ops.push_back({"block7.0.conv1", T_K3, cat7, V(c->b7t), 1, none});
+  ops.push_back({"block7.0.downsample.0", T_LIN, cat7, R(7, 1, 16), 0, none});
+  ops.push_back({"block7.0.conv2", T_K3, V(c->b7t), V(c->b7o), 1, R(7, 1, 16)});
+  ops.push_back({"convtr7p2s2", T_UP, V(c->b7o), cols_of(cat8, 0, 8), 1, none});
+  ops.push_back({"block8.0.conv1", T_K3, cat8, V(c->b8t), 1, none});
+  ops.push_back({"block8.0.downsample.0", T_LIN, cat8, R(8, 0, 8), 0, none});
+  ops.push_back({"block8.0.conv2", T_K3, V(c->b8t), V(c->b8o), 1, R(8, 0, 8)});
+  return ops;
+}
+
+// A plain sparse convolution launch (no BN / residual / fusion): out[o][:] (= or +=) sum_k in[map_k(o)] W'[k], through
+// k_conv (gather maps: 3^4 tables, `down` tables, identity) or k_upconv (parent-stationary over a `down` table).
+//   gather : T_K3 (nbr3 of level_rows), T_DOWN (down table of level_rows: rows = coarse), T_LIN (identity), or
+//            T_UP (k_upconv: rows iterate the COARSE level level_rows, children written at the fine level)
+int conv_plain(sps_ctx *c, hipStream_t st, TKind gather, int level_rows, int K, int cin, int cout, const float *Wu,
+               const float *in, int ldi, float *out, int ldo, bool accumulate) {
+  sps_train *t = c->train;
+  ConvArgs a{};
+  a.in = in;
+  a.ldi = ldi;
+  a.out = out;
+  a.ldo = ldo;
+  a.Wu = Wu;
+  a.scale = t->ones;
+  a.shift = t->zeros;
+  a.res = accumulate ? out : nullptr;
+  a.ldr = ldo;
+  a.ldn = c->cap;
+  a.K = K;
+  a.cin = cin;
+  a.cout = cout;
+  a.NT = (cout + 15) / 16;
+  a.upk = cin / 4;
+  a.inv_upk = 1.0f / (float)a.upk;
+  a.relu = 0;
+  a.in_const = 0.5f;
+  a.S = 1;
+  a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)ldi * 4u);
+  a.wu_bytes = (uint32_t)((size_t)K * a.upk * a.NT * 64 * 4);
+  a.nbr_bytes = (uint32_t)((size_t)K * (size_t)c->cap * 4u);
+  a.tile_cap = (int)(c->cap / 16);
+  a.n_out = c->counts + level_rows;
+  Level &L = c->lv[level_rows];
+  if (gather == T_UP) {
+    a.nbr = L.down;
+    a.tmask = L.tmdown;
+    int64_t gu = (c->cap / 16) >> level_rows;
+    gu = std::min<int64_t>(std::max<int64_t>(gu, 64), 8192);
+    if (a.NT == 1)
+      hipLaunchKernelGGL((k_upconv<1>), dim3((unsigned)gu), dim3(256), 0, st, a);
+    else if (a.NT == 2)
+      hipLaunchKernelGGL((k_upconv<2>), dim3((unsigned)gu), dim3(256), 0, st, a);
+    else if (a.NT == 4)
+      hipLaunchKernelGGL((k_upconv<4>), dim3((unsigned)gu), dim3(256), 0, st, a);
+    else
+      return fail(SPS_ERR_INVALID, "k_upconv: unsupported column count %d", cout);
+    return SPS_OK;
+  }
+  if (gather == T_K3) {
+    a.nbr = L.nbr3;
+    a.tmask = L.tm3;
+  } else if (gather == T_DOWN) {
+    a.nbr = L.down;
+    a.tmask = L.tmdown;
+  }  // T_LIN: identity (nbr = tmask = null)
+  int64_t gx = (c->cap / 64) >> level_rows;
+  gx = std::min<int64_t>(std::max<int64_t>(gx, 64), 4096);
+  const dim3 grid((unsigned)a.NT, (unsigned)gx, 1u);  // one column tile per wave (any NT), no split
+  hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_W1, false, false, 1>), grid, dim3(256), 0, st, a);
+  return SPS_OK;
+}
+
+int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, int cin, int cout, const float *x, int ldx,
+                 const float *dz, int ldz, float *dW) {
+  sps_train *t = c->train;
+  WgradArgs w{};
+  w.x = x;
+  w.ldx = ldx;
+  w.dz = dz;
+  w.ldz = ldz;
+  w.K = K;
+  w.cin = cin;
+  w.cout = cout;
+  w.MT = (cin + 15) / 16;
+  w.NT = (cout + 15) / 16;
+  w.ldn = c->cap;
+  w.n_rows = c->counts + level_rows;
+  w.slab = t->slab;
+  Level &L = c->lv[level_rows];
+  w.gather_b = kind == T_UP ? 1 : 0;
+  if (kind == T_K3) {
+    w.nbr = L.nbr3;
+    w.tmask = L.tm3;
+  } else if (kind == T_DOWN || kind == T_UP) {
+    w.nbr = L.down;
+    w.tmask = L.tmdown;
+  }
+  // rows are cut into chunks (partial sums added in chunk order): enough waves for the fine levels, few for the coarse
+  int nchunk = level_rows <= 1 ? 16 : level_rows == 2 ? 8 : 4;
+  while ((size_t)K * w.MT * w.NT * nchunk * 256 > t->slab_floats && nchunk > 1) nchunk >>= 1;
+  if ((size_t)K * w.MT * w.NT * nchunk * 256 > t->slab_floats) return fail(SPS_ERR_INVALID, "wgrad slab too small");
+  w.nchunk = nchunk;
+  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)((nchunk + 3) / 4), (unsigned)K, (unsigned)(w.MT * w.NT)), dim3(256), 0, st, w);
+  const int total = K * cin * cout;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, t->slab, K, cin, cout,
+                     w.MT, w.NT, nchunk, dW);
+  return SPS_OK;
+}
+
+}  // namespace
+}  // extern "C++"
+
+int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const float *coords, int64_t ld, int64_t n, float vs,
+                      float *scores, float *batch_stats_dev, void *stream) {
+  if (!c || !params_dev || !coords || !scores || n <= 0) return fail(SPS_ERR_INVALID, "bad arguments");
+  const NetSpec &s = spec(1);
+  if (numel != s.numel) return fail(SPS_ERR_INVALID, "parameter blob has %lld floats, expected %lld", (long long)numel, (long long)s.numel);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  // coordinate structures: the inference front-end with the network skipped (weights are not needed for it)
+  {
+    ForwardOpts fo;
+    fo.front_only = true;
+    const NetSpec *saved_net = c->net;
+    const bool saved_have = c->have_weights;
+    c->net = &s;
+    c->have_weights = true;
+    int rc = forward_impl(c, coords, ld, n, vs, scores, fo, stream);
+    c->net = saved_net;
+    c->have_weights = saved_have;
+    if (rc != SPS_OK) return rc;
+  }
+  const NetSpec *saved_net = c->net;
+  c->net = &s;
+  int rc = train_reserve(c);
+  c->net = saved_net;
+  if (rc != SPS_OK) return rc;
+  sps_train *t = c->train;
+  t->have_forward = false;
+  HIP_TRY(hipMemcpyAsync(t->blob, params_dev, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // operands of this step's weights
+  for (size_t i = 0; i < s.convs.size(); ++i) {
+    const ConvSpec &cs = s.convs[i];
+    if (cs.cin == 1 || cs.name == "final") continue;
+    const bool up = cs.name.compare(0, 6, "convtr") == 0;
+    const int tot_f = cs.K * (cs.cin / 4) * ((cs.cout + 15) / 16) * 64, tot_b = cs.K * (cs.cout / 4) * ((cs.cin + 15) / 16) * 64;
+    hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)std::min(512, (tot_f + 255) / 256)), dim3(256), 0, st, t->blob + cs.w_off,
+                       cs.K, cs.cin, cs.cout, 0, t->wu + t->wu_off[i]);
+    // data gradient: symmetric 3^4 maps mirror the offset; stride / transposed / 1x1 maps keep it
+    const int mode = cs.K == 81 ? 1 : 2;
+    (void)up;
+    hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)std::min(512, (tot_b + 255) / 256)), dim3(256), 0, st, t->blob + cs.w_off,
+                       cs.K, cs.cin, cs.cout, mode, t->wut + t->wut_off[i]);
+  }
+  const auto ops = train_ops(c);
+  for (const TOp &op : ops) {
+    const int ci = s.find_conv(op.name);
+    const ConvSpec &cs = s.convs[ci];
+    const int bi = s.find_bn(cs.bn);
+    const BnSpec &bn = s.bns[bi];
+    const int lo = op.out.level;
+    float *z = t->z[ci];
+    if (op.kind == T_CONV0) {
+      hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, c->counts + 0, c->lv[0].view(),
+                         t->blob + cs.w_off, t->ones, t->zeros, 0.5f, z, 8, 0);
+    } else if (op.kind == T_UP) {
+      rc = conv_plain(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
+    } else {
+      rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
+    }
+    if (rc != SPS_OK) return rc;
+    double *part = t->bn_part + (size_t)bi * BN_WG * 2 * BN_MAXC;
+    hipLaunchKernelGGL(k_bn_stats, dim3(BN_WG), dim3(256), 0, st, z, cs.cout, c->counts + lo, cs.cout, part);
+    const float *gamma = t->blob + bn.off, *beta = gamma + bn.c;
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * cs.cout, 256, 1024)), dim3(256), 0, st, z, cs.cout,
+                       c->counts + lo, cs.cout, part, gamma, beta, op.res.p, op.res.ld, op.relu, op.out.p, op.out.ld,
+                       t->batch_stats + cs.ss_off);
+  }
+  // final 1x1 conv + bias, slice, sigmoid (models.py:28-29)
+  const ConvSpec &fs = s.convs[s.find_conv("final")];
+  hipLaunchKernelGGL(k_slice_head, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->b8o, 8, c->lv[0].inv, (int)n,
+                     t->blob + fs.w_off, t->blob + s.bias_off, 1, 1, scores, (int64_t)1);
+  if (batch_stats_dev)
+    HIP_TRY(hipMemcpyAsync(batch_stats_dev, t->batch_stats, (size_t)s.ss_numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  // the block hashes go back to "free" (the inference forward does this in its tail kernel)
+  {
+    const PyramidArgs pa = pyramid_args(c);
+    const int gbc = grid_for(c->cap >> 2, 256, 256);
+    hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
+    c->tables_dirty = false;
+  }
+  HIP_TRY(hipGetLastError());
+  t->n_last = n;
+  t->have_forward = true;
+  return SPS_OK;
+}
+
+int sps_train_backward(sps_ctx *c, const float *dscores, const float *scores, float *grad_dev, int64_t numel, void *stream) {
+  if (!c || !dscores || !scores || !grad_dev) return fail(SPS_ERR_INVALID, "null argument");
+  sps_train *t = c->train;
+  if (!t || !t->have_forward) return fail(SPS_ERR_INVALID, "sps_train_forward has not been called on this context");
+  const NetSpec &s = *t->net;
+  if (numel != s.numel) return fail(SPS_ERR_INVALID, "gradient blob has %lld floats, expected %lld", (long long)numel, (long long)s.numel);
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = t->n_last;
+  HIP_TRY(hipMemsetAsync(t->grad, 0, (size_t)numel * sizeof(float), st));
+  HIP_TRY(hipMemsetAsync(t->gpool, 0, t->gpool_bytes, st));
+  HIP_TRY(hipMemsetAsync(t->vacc, 0, (size_t)c->cap * sizeof(long long), st));
+  // head: sigmoid + slice + final
+  const ConvSpec &fs = s.convs[s.find_conv("final")];
+  const TView b8o = view_of(t, c->b8o);
+  hipLaunchKernelGGL(k_dlogit_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dscores, scores, c->lv[0].inv, (int)n, t->vacc);
+  hipLaunchKernelGGL(k_final_bwd, dim3(BN_WG), dim3(256), 0, st, t->vacc, c->counts + 0, b8o.p, b8o.ld, t->blob + fs.w_off, b8o.g,
+                     b8o.ld, t->fin_part);
+  hipLaunchKernelGGL(k_final_bwd_reduce, dim3(1), dim3(64), 0, st, t->fin_part, t->grad + fs.w_off, t->grad + s.bias_off);
+  const auto ops = train_ops(c);
+  for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
+    const TOp &op = ops[oi];
+    const int ci = s.find_conv(op.name);
+    const ConvSpec &cs = s.convs[ci];
+    const int bi = s.find_bn(cs.bn);
+    const BnSpec &bn = s.bns[bi];
+    const int lo = op.out.level;
+    const float *z = t->z[ci];
+    const double *part = t->bn_part + (size_t)bi * BN_WG * 2 * BN_MAXC;
+    // BN (+ ReLU, + residual) backward: dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG), dim3(256), 0, st, op.out.g, op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout,
+                       c->counts + lo, cs.cout, part, t->bn_bpart);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * cs.cout, 256, 1024)), dim3(256), 0, st, op.out.g,
+                       op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, part, t->bn_bpart,
+                       t->blob + bn.off, t->dz, cs.cout, op.res.g, op.res.ld, t->grad + bn.off, t->grad + bn.off + bn.c);
+    int rc = SPS_OK;
+    if (op.kind == T_CONV0) {
+      const int nwg = 256;
+      hipLaunchKernelGGL(k_conv0_wgrad, dim3(nwg), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
+      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(4), dim3(256), 0, st, t->c0part, nwg, t->grad + cs.w_off);
+      continue;  // the input feature is a constant: no data gradient
+    }
+    // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated
+    if (op.kind == T_UP) {
+      rc = wgrad_launch(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+      if (rc != SPS_OK) return rc;
+      // y[child] = x[parent] W[oct]  =>  dx[parent] += sum over children dy[child] W[oct]^T : a gather over the `down` table
+      rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
+    } else if (op.kind == T_DOWN) {
+      rc = wgrad_launch(c, st, T_DOWN, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+      if (rc != SPS_OK) return rc;
+      // z[parent] = sum over children x[child] W[oct]  =>  dx[child] += dz[parent] W[oct]^T : parent-stationary scatter
+      rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
+    } else {
+      rc = wgrad_launch(c, st, op.kind, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+      if (rc != SPS_OK) return rc;
+      rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
+    }
+    if (rc != SPS_OK) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(grad_dev, t->grad, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}

@@ -1,0 +1,384 @@
+// train_kernels.inc.h -- part of the single translation unit sps_hip.hip (included inside its anonymous namespace).
+// Training path (reference src/sps/models/models.py:62-82 common_step / training_step): train-mode
+// BatchNorm (batch statistics), backward of BN / ReLU / residual, weight gradient of the sparse convolutions,
+// backward of slice + sigmoid.  The data gradient of a sparse convolution is itself a sparse convolution over the
+// SAME kernel map with mirrored, transposed weights (k_conv / k_upconv are reused for it, see train_backward()).
+// Every reduction is a fixed-order tree (per-workgroup partials combined in index order, f64): a training step is
+// bit-reproducible run to run, like the forward.
+
+// ------------------------------------------------------------------------------------------
+// weights: flat parameter blob (reference state_dict order, [K][C_in][C_out] kernels) -> MFMA unit-major operands
+// ------------------------------------------------------------------------------------------
+// Wu[u][nt][n][s] = W'[k][4 c4 + s][16 nt + n], u = k * upk' + c4, for the (possibly mirrored / transposed) kernel
+//   mode 0: W'[k][ci][co] = W[k][ci][co]            (forward operand; C_in' = C_in,  C_out' = C_out)
+//   mode 1: W'[k][co][ci] = W[K - 1 - k][ci][co]    (data gradient over a symmetric 3^4 map; C_in' = C_out, C_out' = C_in)
+//   mode 2: W'[k][co][ci] = W[k][ci][co]            (data gradient over a stride map: same octant, transposed)
+__global__ void k_permute_weights(const float *__restrict__ W, int K, int cin, int cout, int mode, float *__restrict__ Wu) {
+  const int cin2 = mode == 0 ? cin : cout, cout2 = mode == 0 ? cout : cin;
+  const int upk = cin2 / 4, NT = (cout2 + 15) / 16;
+  const int total = K * upk * NT * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int s = i & 3, n = (i >> 2) & 15;
+    const int rest = i >> 6;
+    const int nt = rest % NT, u = rest / NT;
+    const int k = u / upk, c4 = u - k * upk;
+    const int a = 4 * c4 + s, b = 16 * nt + n;  // a: row of W' (input channel of this operand), b: its column
+    float v = 0.f;
+    if (b < cout2) {
+      if (mode == 0) v = W[((size_t)k * cin + a) * cout + b];
+      else if (mode == 1) v = W[((size_t)(K - 1 - k) * cin + b) * cout + a];
+      else v = W[((size_t)k * cin + b) * cout + a];
+    }
+    Wu[i] = v;
+  }
+}
+
+// conv0p1s1 operand of k_conv0_fused: [125][8] raw kernel rows (C_in = 1): it reads the blob directly; nothing to do.
+
+// ------------------------------------------------------------------------------------------
+// train-mode BatchNorm (ME.MinkowskiBatchNorm = nn.BatchNorm1d over the V active rows; resnet.py:93-94, eps = 1e-5)
+// ------------------------------------------------------------------------------------------
+constexpr int BN_WG = 64;      // partial-sum workgroups per reduction (fixed: the combine order is part of the result)
+constexpr int BN_MAXC = 96;
+
+// pass 1: per workgroup, per channel: sum z and sum z^2 over its contiguous slice of rows (f64)
+__global__ __launch_bounds__(256) void k_bn_stats(const float *__restrict__ Z, int ld, const int *__restrict__ n_rows, int C,
+                                                   double *__restrict__ part /* [BN_WG][2][C] */) {
+  __shared__ double red[2][4][BN_MAXC];
+  const int n = *n_rows;
+  const int per = (n + BN_WG - 1) / BN_WG;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // a wave walks rows r0 + wave, +4, ...; lane c (and c + 64) owns channel c
+  double s0[2] = {0, 0}, s1[2] = {0, 0};
+  for (int r = r0 + wave; r < r1; r += 4) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < C) {
+        const double v = (double)Z[(size_t)r * ld + c];
+        s0[h] += v;
+        s1[h] += v * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = lane + 64 * h;
+    if (c < C) {
+      red[0][wave][c] = s0[h];
+      red[1][wave][c] = s1[h];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int w = i / C, c = i - w * C;
+    part[((size_t)blockIdx.x * 2 + w) * C + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+  }
+}
+
+// combine the BN_WG partials in index order -> mean / invstd of channel c (every workgroup of the consumer recomputes
+// them: BN_WG * C adds, cheaper than a launch).  Also the batch statistics the host folds into running_mean / _var.
+__device__ inline void bn_finish(const double *__restrict__ part, int C, int n, int c, float &mean, float &invstd,
+                                 float *__restrict__ batch_stats /* [2][C]: mean, biased var; or null */) {
+  double s0 = 0, s1 = 0;
+  for (int w = 0; w < BN_WG; ++w) {
+    s0 += part[((size_t)w * 2 + 0) * C + c];
+    s1 += part[((size_t)w * 2 + 1) * C + c];
+  }
+  const double m = n > 0 ? s0 / n : 0.0;
+  double var = n > 0 ? s1 / n - m * m : 0.0;
+  if (var < 0) var = 0;
+  mean = (float)m;
+  invstd = (float)(1.0 / sqrt(var + 1e-5));
+  if (batch_stats) {
+    batch_stats[c] = (float)m;
+    batch_stats[C + c] = (float)var;
+  }
+}
+
+// pass 2: y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, int ldz, const int *__restrict__ n_rows, int C,
+                                                   const double *__restrict__ part, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, const float *__restrict__ res, int ldr,
+                                                   int relu, float *__restrict__ Y, int ldy, float *__restrict__ batch_stats) {
+  __shared__ float sc[BN_MAXC], sh[BN_MAXC];
+  const int n = *n_rows;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mean, invstd;
+    bn_finish(part, C, n, c, mean, invstd, blockIdx.x == 0 ? batch_stats : nullptr);
+    sc[c] = invstd * gamma[c];
+    sh[c] = beta[c] - mean * invstd * gamma[c];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)n * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+    float y = Z[(size_t)r * ldz + c] * sc[c] + sh[c];
+    if (res) y += res[(size_t)r * ldr + c];
+    if (relu) y = fmaxf(y, 0.f);
+    Y[(size_t)r * ldy + c] = y;
+  }
+}
+
+// backward pass 1: dA = dY * (Y > 0 if relu); per channel sum dA and sum dA * xhat (xhat = (z - mean) * invstd)
+__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
+                                                       int relu, const float *__restrict__ Z, int ldz,
+                                                       const int *__restrict__ n_rows, int C, const double *__restrict__ part,
+                                                       double *__restrict__ bpart /* [BN_WG][2][C] */) {
+  __shared__ double red[2][4][BN_MAXC];
+  __shared__ float mean_s[BN_MAXC], inv_s[BN_MAXC];
+  const int n = *n_rows;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) bn_finish(part, C, n, c, mean_s[c], inv_s[c], nullptr);
+  __syncthreads();
+  const int per = (n + BN_WG - 1) / BN_WG;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double s0[2] = {0, 0}, s1[2] = {0, 0};
+  for (int r = r0 + wave; r < r1; r += 4) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = lane + 64 * h;
+      if (c < C) {
+        float g = dY[(size_t)r * ldg + c];
+        if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+        const float xh = (Z[(size_t)r * ldz + c] - mean_s[c]) * inv_s[c];
+        s0[h] += (double)g;
+        s1[h] += (double)g * (double)xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = lane + 64 * h;
+    if (c < C) {
+      red[0][wave][c] = s0[h];
+      red[1][wave][c] = s1[h];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    const int w = i / C, c = i - w * C;
+    bpart[((size_t)blockIdx.x * 2 + w) * C + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+  }
+}
+
+// backward pass 2: dZ = gamma * invstd * (dA - mean(dA) - xhat * mean(dA * xhat)); dgamma = sum dA xhat, dbeta = sum dA;
+// the masked gradient dA is also ADDED to dres (the gradient of the residual operand), when given.
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
+                                                       int relu, const float *__restrict__ Z, int ldz,
+                                                       const int *__restrict__ n_rows, int C, const double *__restrict__ part,
+                                                       const double *__restrict__ bpart, const float *__restrict__ gamma,
+                                                       float *__restrict__ dZ, int lddz, float *__restrict__ dres, int lddr,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta) {
+  __shared__ float mean_s[BN_MAXC], inv_s[BN_MAXC], k1_s[BN_MAXC], k2_s[BN_MAXC], gi_s[BN_MAXC];
+  const int n = *n_rows;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    bn_finish(part, C, n, c, mean_s[c], inv_s[c], nullptr);
+    double s0 = 0, s1 = 0;
+    for (int w = 0; w < BN_WG; ++w) {
+      s0 += bpart[((size_t)w * 2 + 0) * C + c];
+      s1 += bpart[((size_t)w * 2 + 1) * C + c];
+    }
+    if (blockIdx.x == 0) {
+      dbeta[c] = (float)s0;
+      dgamma[c] = (float)s1;
+    }
+    k1_s[c] = n > 0 ? (float)(s0 / n) : 0.f;
+    k2_s[c] = n > 0 ? (float)(s1 / n) : 0.f;
+    gi_s[c] = gamma[c] * inv_s[c];
+  }
+  __syncthreads();
+  const int64_t total = (int64_t)n * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
+    float g = dY[(size_t)r * ldg + c];
+    if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+    const float xh = (Z[(size_t)r * ldz + c] - mean_s[c]) * inv_s[c];
+    dZ[(size_t)r * lddz + c] = gi_s[c] * (g - k1_s[c] - xh * k2_s[c]);
+    if (dres) dres[(size_t)r * lddr + c] += g;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradient of a sparse convolution: dW[k][ci][co] = sum over the pairs (i, o) of offset k of x[i][ci] * dz[o][co]
+// ------------------------------------------------------------------------------------------
+// One wave = one 16 x 16 tile (mt, nt) of dW[k] over one chunk of the map's rows; MFMA 16x16x4 with the PAIRS as the
+// contraction dimension: lane (m, q) feeds A[m][q] = x[i_q][16 mt + m] and B[q][n] = dz[o_q][16 nt + n] for the four
+// rows o = o0 + q of a step.  Tiles of 16 rows whose mask lacks offset k are skipped.
+//   gather_b = 0: i = nbr[k][o], o = row      (3^4 convs and stride-2 convs: the map gathers the INPUT)
+//   gather_b = 1: i = row, o = nbr[k][row]    (transposed convs: the `down` table of the coarse level lists the OUTPUT rows)
+// Partials go to slab[((k * MT + mt) * NT + nt) * nchunk + chunk][16][16]; k_wgrad_reduce adds the chunks in order.
+struct WgradArgs {
+  const float *x;   // [*, ldx] operand indexed by i
+  const float *dz;  // [*, ldz] operand indexed by o
+  const int *nbr;   // [K][ldn] or null (1x1: i = o = row)
+  const uint32_t *tmask;
+  const int *n_rows;  // rows of the map (device count)
+  float *slab;
+  int64_t ldn;
+  int ldx, ldz, K, cin, cout, MT, NT, nchunk, gather_b;
+};
+
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 15, q = lane >> 4;
+  const int n = *a.n_rows;
+  const int ntiles = (n + 15) >> 4;
+  const int k = blockIdx.y;
+  const int tile_id = blockIdx.z;  // mt * NT + nt
+  const int mt = tile_id / a.NT, nt = tile_id - mt * a.NT;
+  const int chunk = blockIdx.x * 4 + wave;
+  if (chunk >= a.nchunk) return;
+  const int per = (ntiles + a.nchunk - 1) / a.nchunk;
+  const int t0 = chunk * per, t1 = min(ntiles, t0 + per);
+  const int ca = mt * 16 + m, cb = nt * 16 + m;
+  const bool va = ca < a.cin, vb = cb < a.cout;
+  floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+  for (int t = t0; t < t1; ++t) {
+    if (a.tmask) {
+      const uint32_t w = a.tmask[(size_t)t * 4 + k / 27];  // one word per time slice (27 offsets); K = 8 maps: word 0
+      if (!((w >> (k % 27)) & 1u)) continue;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int row = t * 16 + 4 * s + q;
+      int other = row < n ? row : -1;
+      if (a.nbr && row < n) other = a.nbr[(size_t)k * a.ldn + row];
+      const int i = a.gather_b ? (row < n ? row : -1) : other;
+      const int o = a.gather_b ? other : (row < n ? row : -1);
+      const bool ok = i >= 0 && o >= 0;
+      const float av = (ok && va) ? a.x[(size_t)i * a.ldx + ca] : 0.f;
+      const float bv = (ok && vb) ? a.dz[(size_t)o * a.ldz + cb] : 0.f;
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+    }
+  }
+  // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+  float *dst = a.slab + (((size_t)k * a.MT * a.NT + tile_id) * a.nchunk + chunk) * 256;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) dst[(q * 4 + i) * 16 + m] = acc[i];
+}
+
+__global__ void k_wgrad_reduce(const float *__restrict__ slab, int K, int cin, int cout, int MT, int NT, int nchunk,
+                               float *__restrict__ dW /* [K][cin][cout] */) {
+  const int total = K * cin * cout;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int co = i % cout, ci = (i / cout) % cin, k = i / (cout * cin);
+    const int mt = ci >> 4, nt = co >> 4;
+    const float *src = slab + (((size_t)k * MT * NT + mt * NT + nt) * nchunk) * 256 + (ci & 15) * 16 + (co & 15);
+    float s = 0.f;
+    for (int c = 0; c < nchunk; ++c) s += src[(size_t)c * 256];
+    dW[i] = s;
+  }
+}
+
+// conv0p1s1 (5x5x5x1, C_in = 1, constant input 0.5): dW[k][0][co] = 0.5 * sum over the rows that HAVE neighbour k of dz[row][co].
+// One thread per (row, run of five x-neighbours): presence from the block masks exactly as k_conv0_fused reads them;
+// sums per workgroup in LDS (integer-free f32 adds in a fixed order are not possible with atomics, so: per-workgroup
+// partials by a fixed tree, combined in order by k_conv0_wgrad_reduce).
+__global__ __launch_bounds__(256) void k_conv0_wgrad(const int *__restrict__ n_out, LevelView L, const float *__restrict__ dz, int ldz,
+                                                      float in_const, float *__restrict__ part /* [grid][125][8] */) {
+  __shared__ float acc_s[4][125 * 8];
+  const int n = *n_out;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = lane; i < 125 * 8; i += 64) acc_s[wave][i] = 0.f;
+  __builtin_amdgcn_wave_barrier();
+  // a wave takes rows one at a time (fixed order); lane c < 25 handles run c of the row, lanes 32..39 hold dz[row][0..7]
+  const int per = (n + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
+  const int w = blockIdx.x * 4 + wave;
+  const int r0 = w * per, r1 = min(n, r0 + per);
+  for (int u = r0; u < r1; ++u) {
+    uint32_t pres = 0u;
+    if (lane < 25) {
+      const int blk = L.vblock[u];
+      const int bit = L.vbit[u];
+      const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+      const int c = lane;
+      const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
+      const int bo_lo = px < 2 ? -1 : 0;
+      const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
+      const int *adj = L.badj + (size_t)blk * 81;
+      const int nb0 = adj[ad0], nb1 = adj[ad0 + 1];
+      const int sh = ((tz & 3) << 4) | ((ty & 3) << 2);
+      const uint32_t m0 = nb0 >= 0 ? (uint32_t)((L.bmask[nb0] >> sh) & 0xFull) : 0u;
+      const uint32_t m1 = nb1 >= 0 ? (uint32_t)((L.bmask[nb1] >> sh) & 0xFull) : 0u;
+      pres = ((m0 | (m1 << 4)) >> (px - 2 - 4 * bo_lo)) & 0x1Fu;
+    }
+    float g[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] = dz[(size_t)u * ldz + j] * in_const;  // every lane reads the same 32 bytes
+    if (lane < 25) {
+#pragma unroll
+      for (int dx = 0; dx < 5; ++dx)
+        if ((pres >> dx) & 1u) {
+          float *d = acc_s[wave] + (5 * lane + dx) * 8;  // k = 5 c + (dx + 2), private to this lane
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d[j] += g[j];
+        }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 125 * 8; i += blockDim.x)
+    part[(size_t)blockIdx.x * 1000 + i] = (acc_s[0][i] + acc_s[1][i]) + (acc_s[2][i] + acc_s[3][i]);
+}
+__global__ void k_conv0_wgrad_reduce(const float *__restrict__ part, int nwg, float *__restrict__ dW /* [125][1][8] */) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 1000) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; ++w) s += part[(size_t)w * 1000 + i];
+  dW[i] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// head of the backward: scores = sigmoid(logits[inv]) (models.py:28-29), logits = b8o . w + b (minkunet.py:152-158)
+// ------------------------------------------------------------------------------------------
+// dlogit[v] = sum over the points p of voxel v of dscores[p] * s_p (1 - s_p): 32.32 fixed-point integer atomics, so
+// the sum does not depend on the arrival order (|term| < 2^15; resolution 2^-32).
+__global__ void k_dlogit_accum(const float *__restrict__ dscores, const float *__restrict__ scores, const int *__restrict__ inv,
+                               int n, long long *__restrict__ vacc) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const int v = inv[p];
+  if (v < 0) return;
+  const float s = scores[p];
+  const double t = fmin(fmax((double)dscores[p] * (double)s * (double)(1.f - s), -32768.0), 32768.0);
+  if (t != 0.0) atomicAdd(reinterpret_cast<unsigned long long *>(vacc) + v, (unsigned long long)__double2ll_rn(t * FEAT_FIX));
+}
+
+// final 1x1 conv: dlogit -> db8o[v][c] = dlogit[v] * w[c]; per-workgroup partials of dw[c] = sum dlogit * b8o[v][c], db = sum dlogit
+__global__ __launch_bounds__(256) void k_final_bwd(const long long *__restrict__ vacc, const int *__restrict__ n_rows,
+                                                    const float *__restrict__ F, int ldf, const float *__restrict__ w,
+                                                    float *__restrict__ dF, int ldd, double *__restrict__ part /* [BN_WG][9] */) {
+  __shared__ double red[9][256];
+  const int n = *n_rows;
+  const int per = (n + BN_WG - 1) / BN_WG;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int v = r0 + (int)threadIdx.x; v < r1; v += blockDim.x) {
+    const float dl = (float)((double)vacc[v] / FEAT_FIX);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      dF[(size_t)v * ldd + c] = dl * w[c];
+      s[c] += (double)dl * (double)F[(size_t)v * ldf + c];
+    }
+    s[8] += (double)dl;
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) red[j][threadIdx.x] = s[j];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int j = 0; j < 9; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 9) part[(size_t)blockIdx.x * 9 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ void k_final_bwd_reduce(const double *__restrict__ part, float *__restrict__ dw /* [8] */, float *__restrict__ db) {
+  const int j = threadIdx.x;
+  if (j >= 9) return;
+  double s = 0;
+  for (int w = 0; w < BN_WG; ++w) s += part[(size_t)w * 9 + j];
+  if (j < 8) dw[j] = (float)s;
+  else db[0] = (float)s;
+}

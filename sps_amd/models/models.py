@@ -8,8 +8,9 @@
 Same names, argument meaning and state_dict keys; the arithmetic (quantise, voxel hash, kernel
 maps, 33 sparse convs + BN, slice, sigmoid, metric sums) runs in hand-written HIP kernels
 (sps_amd/csrc/sps_hip.hip) through the C ABI of include/sps_hip.h.  There is no CPU fallback:
-a CPU tensor raises.  SPSNet is a plain nn.Module (pytorch_lightning is not a dependency);
-training (models.py:62-82,154-160) is out of scope.
+a CPU tensor raises.  SPSNet is a plain nn.Module (pytorch_lightning is not a dependency) with the
+LightningModule hooks the reference defines (forward, common_step, training_step, validation_step, predict_step,
+configure_optimizers); in ``.train()`` mode the forward is differentiable (train-mode BatchNorm, native backward).
 """
 from __future__ import annotations
 
@@ -106,6 +107,60 @@ class NativeBackboneModule(nn.Module):
         return coordinates
 
 
+def _bn_of_conv(conv: str) -> str:
+    """state_dict prefix of the BatchNorm that follows conv `conv` (minkunet.py:55-159, resnet BasicBlock)."""
+    if conv == "conv0p1s1":
+        return "bn0"
+    if conv.startswith("convtr"):
+        return "bntr" + conv[len("convtr")]
+    if conv.startswith("conv") and conv[4].isdigit():
+        return "bn" + conv[4]
+    return conv.replace("conv1", "norm1").replace("conv2", "norm2").replace("downsample.0", "downsample.1")
+
+
+class _TrainForward(torch.autograd.Function):
+    """Train-mode forward / backward of the SPS network through libsps_hip.so (sps_train_forward / _backward): the
+    autograd node that stands where the reference has MinkowskiEngine's autograd functions (models.py:62-76)."""
+
+    @staticmethod
+    def forward(fctx, module, coordinates, *params):
+        dev = coordinates.device
+        oc = module.MinkUNet.out_channels
+        layout = _native.weight_layout(oc)
+        sd = module.MinkUNet.state_dict(keep_vars=True)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            ctx = get_context(dev.index or 0, stream)
+            blob = torch.cat([sd[name].detach().reshape(-1).to(torch.float32) for name, _, _ in layout])
+            n = coordinates.shape[0]
+            scores = torch.empty(n, dtype=torch.float32, device=dev)
+            n_stats = 2 * sum(int(sd[name].shape[-1]) for name, _, _ in layout if name.endswith(".kernel"))
+            stats = torch.zeros(n_stats, dtype=torch.float32, device=dev)
+            ctx.train_forward(blob.data_ptr(), blob.numel(), coordinates.data_ptr(), coordinates.stride(0), n,
+                              module.voxel_size, scores.data_ptr(), stats.data_ptr(), stream)
+        fctx.save_for_backward(scores)
+        fctx.native = (ctx, layout, [(id(p), tuple(p.shape)) for p in params], {name: id(sd[name]) for name, _, _ in layout},
+                       blob.numel())
+        fctx.mark_non_differentiable(stats)
+        return scores, stats
+
+    @staticmethod
+    def backward(fctx, dscores, _dstats):
+        (scores,) = fctx.saved_tensors
+        ctx, layout, param_ids, name_ids, numel = fctx.native
+        with torch.cuda.device(scores.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            grad = torch.empty(numel, dtype=torch.float32, device=scores.device)
+            d = dscores.to(torch.float32).contiguous()
+            ctx.train_backward(d.data_ptr(), scores.data_ptr(), grad.data_ptr(), numel, stream)
+        by_id = {name_ids[name]: (off, num) for name, off, num in layout}
+        out = []
+        for (pid, shape), need in zip(param_ids, fctx.needs_input_grad[2:]):
+            off, num = by_id[pid]
+            out.append(grad[off: off + num].view(shape) if need else None)
+        return (None, None, *out)
+
+
 class SPSModel(NativeBackboneModule):
     def __init__(self, voxel_size: float):
         super().__init__()
@@ -117,8 +172,12 @@ class SPSModel(NativeBackboneModule):
 
     # ---- forward --------------------------------------------------------------------------
     def forward(self, coordinates: torch.Tensor) -> torch.Tensor:
-        """coordinates: float32 [N, >=5] rows (b, x, y, z, t); returns scores float32 [N]."""
+        """coordinates: float32 [N, >=5] rows (b, x, y, z, t); returns scores float32 [N].
+        In training mode (``.train()``, gradients enabled) the forward runs train-mode BatchNorm and is differentiable
+        with respect to every parameter (sps_train_forward / sps_train_backward); otherwise the inference path."""
         coordinates = self._prepare_coordinates(coordinates)
+        if self.training and torch.is_grad_enabled():
+            return self._train_forward(coordinates)
         with torch.cuda.device(coordinates.device):
             stream = torch.cuda.current_stream().cuda_stream
             ctx = get_context(coordinates.device.index or 0, stream)
@@ -128,6 +187,40 @@ class SPSModel(NativeBackboneModule):
             ctx.forward(coordinates.data_ptr(), coordinates.stride(0) if n else 5, n, self.voxel_size,
                         scores.data_ptr(), stream)
         return scores
+
+    def _train_forward(self, coordinates: torch.Tensor) -> torch.Tensor:
+        if coordinates.shape[0] == 0:
+            raise ValueError("a training step needs at least one point")
+        params = [p for p in self.MinkUNet.parameters()]
+        scores, stats = _TrainForward.apply(self, coordinates, *params)
+        self._update_running_stats(coordinates.device, stats)
+        self.mark_weights_dirty()          # the optimiser is about to change the parameters: eval contexts re-upload
+        return scores
+
+    @torch.no_grad()
+    def _update_running_stats(self, device, stats: torch.Tensor) -> None:
+        """nn.BatchNorm1d bookkeeping in train mode: running = (1 - m) running + m batch (m = 0.1, unbiased variance),
+        num_batches_tracked += 1.  The per-level row counts come from the context (one synchronisation per step)."""
+        ctx = get_context(device.index or 0, torch.cuda.current_stream(device).cuda_stream)
+        counts = ctx.level_counts()
+        level_of = {"bn0": 0, "bn1": 1, "bn2": 2, "bn3": 3, "bn4": 4, "bntr4": 3, "bntr5": 2, "bntr6": 1, "bntr7": 0,
+                    "block1": 1, "block2": 2, "block3": 3, "block4": 4, "block5": 3, "block6": 2, "block7": 1, "block8": 0}
+        sd = self.MinkUNet.state_dict(keep_vars=True)
+        off = 0
+        for name, _, _ in _native.weight_layout(self.MinkUNet.out_channels):
+            if not name.endswith(".kernel"):
+                continue
+            conv = name[: -len(".kernel")]
+            c = int(sd[name].shape[-1])
+            if conv != "final":
+                bn = _bn_of_conv(conv)
+                n = counts[level_of[bn.split(".")[0]]]
+                mean, var = stats[off: off + c], stats[off + c: off + 2 * c]
+                m = 0.1
+                sd[bn + ".bn.running_mean"].mul_(1 - m).add_(mean, alpha=m)
+                sd[bn + ".bn.running_var"].mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
+                sd[bn + ".bn.num_batches_tracked"].add_(1)
+            off += 2 * c
 
 
 class SPSNet(nn.Module):
@@ -146,6 +239,7 @@ class SPSNet(nn.Module):
         self.recall = []
         self.F1 = []
         self.data_size = data_size
+        self.loss = nn.MSELoss()                 # models.py:52
 
     def freeze(self):
         for p in self.parameters():
@@ -154,6 +248,38 @@ class SPSNet(nn.Module):
 
     def forward(self, batch: torch.Tensor) -> torch.Tensor:
         return self.model(batch[:, :5])          # strided view: no copy crosses the boundary
+
+    # ---- training (models.py:62-82, :154-160) -------------------------------------------------------------------
+    @staticmethod
+    def r2score(preds: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """torchmetrics.R2Score: 1 - sum (y - p)^2 / sum (y - mean y)^2."""
+        ss_res = torch.sum((target - preds) ** 2)
+        ss_tot = torch.sum((target - target.mean()) ** 2)
+        return 1.0 - ss_res / ss_tot
+
+    def common_step(self, batch: torch.Tensor):
+        coordinates = batch[:, :5].reshape(-1, 5)
+        gt_labels = batch[:, 5].reshape(-1)
+        scan_indices = torch.nonzero(coordinates[:, 4] == 1).reshape(-1)        # np.where(t == 1) on the host in the reference
+        scores = self.model(coordinates)
+        loss = self.loss(scores[scan_indices], gt_labels[scan_indices])
+        r2 = self.r2score(scores[scan_indices].detach(), gt_labels[scan_indices])
+        return loss, r2
+
+    def training_step(self, batch: torch.Tensor, batch_idx: int, dataloader_idx: int = 0):
+        loss, r2 = self.common_step(batch)
+        return {"loss": loss, "val_r2": r2}
+
+    def validation_step(self, batch: torch.Tensor, batch_idx: int):
+        loss, r2 = self.common_step(batch)
+        return {"val_loss": loss, "val_r2": r2}
+
+    def configure_optimizers(self):
+        optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams["TRAIN"]["LR"],
+                                     weight_decay=self.hparams["TRAIN"]["WEIGHT_DECAY"])
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.hparams["TRAIN"]["LR_EPOCH"],
+                                                    gamma=self.hparams["TRAIN"]["LR_DECAY"])
+        return [optimizer], [scheduler]
 
     @torch.no_grad()
     def forward_metrics(self, batch: torch.Tensor, n_batches: int = 1, out: torch.Tensor | None = None):

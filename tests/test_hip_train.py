@@ -1,0 +1,99 @@
+"""GPU parity tests of the training path: sps_train_forward / sps_train_backward behind
+SPSNet.training_step against torch.autograd on the CPU restatement (oracle/train_oracle.py) -- same coordinate sets and
+kernel maps as the inference oracle, gradients from an independent implementation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import sps_oracle as O
+from oracle import train_oracle as T
+from sps_amd import synthetic
+from tests.helpers import CFG, net_from_params
+
+pytestmark = pytest.mark.gpu
+VS = CFG["MODEL"]["VOXEL_SIZE"]
+
+
+def rel_err(got, want):
+    return float(np.max(np.abs(got - want)) / max(np.max(np.abs(want)), 1e-12))
+
+
+def native_step(params, batch):
+    net = net_from_params(params).cuda().train()
+    dev = torch.from_numpy(batch).cuda()
+    out = net.training_step(dev, 0)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    grads = {k.replace("model.MinkUNet.", ""): p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}
+    return net, out, grads
+
+
+@pytest.mark.timeout(600)
+def test_training_step_gradients_match_autograd_oracle():
+    batch = synthetic.small_scene(seed=3, n_scan=900)
+    params = O.random_params(seed=0)
+    loss_ref, scores_ref, grads_ref, stats_ref = T.train_step(params, batch, VS)
+    net, out, grads = native_step(params, batch)
+    assert float(out["loss"]) == pytest.approx(loss_ref, rel=2e-5)
+    net.train()
+    with torch.enable_grad():
+        s = net(torch.from_numpy(batch).cuda()).detach().cpu().numpy()
+    np.testing.assert_allclose(s, scores_ref, rtol=0, atol=2e-5)          # train-mode BatchNorm forward
+    assert set(grads) == set(grads_ref)
+    worst = {}
+    for name, want in grads_ref.items():
+        got = grads[name].reshape(want.shape)
+        assert np.isfinite(got).all(), name
+        worst[name] = rel_err(got, want)
+    bad = {k: v for k, v in worst.items() if v > 2e-3}
+    assert not bad, f"gradient mismatch (relative to the tensor's max): {bad}"
+    # every kind of layer carries a non-trivial gradient
+    for k in ("conv0p1s1.kernel", "conv1p1s2.kernel", "block1.0.conv1.kernel", "block4.0.downsample.0.kernel",
+              "convtr4p16s2.kernel", "block8.0.conv2.kernel", "block5.0.norm2.bn.weight", "bn0.bn.bias", "final.kernel", "final.bias"):
+        assert np.abs(grads_ref[k]).max() > 0, k
+
+
+@pytest.mark.timeout(600)
+def test_running_statistics_follow_batchnorm1d():
+    batch = synthetic.small_scene(seed=5, n_scan=700)
+    params = O.random_params(seed=1)
+    _, _, _, stats_ref = T.train_step(params, batch, VS)
+    net, _, _ = native_step(params, batch)
+    sd = {k.replace("model.MinkUNet.", ""): v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    for bn, (mean, var, n) in stats_ref.items():
+        want_m = 0.9 * params[bn + ".bn.running_mean"] + 0.1 * mean
+        want_v = 0.9 * params[bn + ".bn.running_var"] + 0.1 * var * (n / max(n - 1, 1))
+        np.testing.assert_allclose(sd[bn + ".bn.running_mean"], want_m, rtol=0, atol=2e-5, err_msg=bn)
+        np.testing.assert_allclose(sd[bn + ".bn.running_var"], want_v, rtol=2e-4, atol=2e-5, err_msg=bn)
+        assert int(sd[bn + ".bn.num_batches_tracked"]) == 1
+
+
+@pytest.mark.timeout(600)
+def test_training_is_deterministic_and_reduces_the_loss():
+    batch = synthetic.small_scene(seed=8, n_scan=1500)
+    params = O.random_params(seed=2)
+    _, o1, g1 = native_step(params, batch)
+    _, o2, g2 = native_step(params, batch)
+    assert float(o1["loss"]) == float(o2["loss"])
+    for k in g1:
+        np.testing.assert_array_equal(g1[k], g2[k], err_msg=k)            # fixed-order reductions: same bits every run
+    cfg = dict(CFG)
+    cfg["TRAIN"] = dict(CFG["TRAIN"], LR=2e-3)
+    net = net_from_params(params, cfg).cuda().train()
+    (opt,), (sched,) = net.configure_optimizers()
+    dev = torch.from_numpy(batch).cuda()
+    losses = []
+    for step in range(12):
+        opt.zero_grad()
+        out = net.training_step(dev, step)
+        out["loss"].backward()
+        opt.step()
+        losses.append(float(out["loss"]))
+    assert losses[-1] < 0.7 * losses[0], losses
+    # eval mode afterwards uses the updated parameters and running statistics through the inference path
+    net.eval()
+    with torch.no_grad():
+        s = net(dev)
+    assert torch.isfinite(s).all() and s.shape == (len(batch),)
+    v = net.validation_step(dev, 0)
+    assert set(v) == {"val_loss", "val_r2"}
