@@ -15,6 +15,7 @@ _ALIASES = {
     "sps.datasets": "sps_amd.datasets",
     "sps.datasets.util": "sps_amd.datasets.util",
     "sps.datasets.blt_dataset": "sps_amd.datasets.blt_dataset",
+    "sps.datasets.augmentation": "sps_amd.datasets.augmentation",
 }
 for _alias, _target in _ALIASES.items():
     sys.modules[_alias] = importlib.import_module(_target)

@@ -4,7 +4,7 @@
 ("variant A", :224-226,258-271) and the collate layout [N,6]=(b,x,y,z,t,label) (:173-182).
 
 pytorch_lightning is not a dependency: BacchusModule is a plain class with the same methods.
-Training-time augmentation (:241-242,273-278) is out of scope (inference path only).
+Training-time augmentation (:241-242,273-278) lives in ``augmentation.py`` and is applied to the training split only.
 """
 from __future__ import annotations
 
@@ -15,7 +15,7 @@ import torch
 from scipy.spatial import cKDTree
 from torch.utils.data import DataLoader, Dataset
 
-from . import util
+from . import augmentation, util
 
 
 class BacchusModule:
@@ -105,9 +105,7 @@ class BacchusDataset(Dataset):
         self.dataset_size = len(scans)
         self.map = pc_map
         self.kd_tree_target = cKDTree(self.map[:, :3])          # built once (:198)
-        if self.cfg["TRAIN"]["AUGMENTATION"] and split == "train":
-            raise NotImplementedError("training-time augmentation is out of scope of the MI355X inference path")
-        self.augment = False
+        self.augment = bool(self.cfg["TRAIN"]["AUGMENTATION"]) and split == "train"          # :200-204
 
     def __len__(self):
         return self.dataset_size
@@ -122,7 +120,17 @@ class BacchusDataset(Dataset):
         submap_idx = self.select_closest_points(cKDTree(scan[:, :3]), self.kd_tree_target)
         sub_xyz = torch.tensor(self.map[submap_idx, :3]).to(torch.float32).reshape(-1, 3)
         sub_rows = torch.hstack([self.add_timestamp(sub_xyz, util.MAP_TIMESTAMP), torch.ones(sub_xyz.shape[0], 1)])
-        return torch.vstack([scan_rows, sub_rows])
+        item = torch.vstack([scan_rows, sub_rows])
+        if self.augment:                                             # :240-242, training split only
+            item[:, :3] = self.augment_data(item[:, :3])
+        return item
+
+    def augment_data(self, scan_map_batch):
+        """:273-278 -- yaw, small rotation, mirror, scale of scan and submap together."""
+        for step in (augmentation.rotate_point_cloud, augmentation.rotate_perturbation_point_cloud,
+                     augmentation.random_flip_point_cloud, augmentation.random_scale_point_cloud):
+            scan_map_batch = step(scan_map_batch)
+        return scan_map_batch
 
     def add_timestamp(self, data, stamp):
         return torch.hstack([data, torch.full((len(data), 1), stamp, dtype=data.dtype)])

@@ -97,3 +97,27 @@ def test_training_is_deterministic_and_reduces_the_loss():
     assert torch.isfinite(s).all() and s.shape == (len(batch),)
     v = net.validation_step(dev, 0)
     assert set(v) == {"val_loss", "val_r2"}
+
+
+@pytest.mark.timeout(900)
+def test_train_cli_writes_a_checkpoint_predict_cli_loads(tmp_path):
+    """scripts/train.py --synthetic: two epochs, loss printed per epoch, Lightning-layout checkpoints; scripts/predict.py -w
+    loads the result (predict.py:56-58)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "train.py"), "-c", os.path.join(root, "config", "config.yaml"),
+                        "--synthetic", "6", "--max-epochs", "2", "--out", str(tmp_path)], capture_output=True, text=True,
+                       timeout=800, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 2 and "val_loss" in lines[0]
+    ck = os.path.join(str(tmp_path), "BLT", "checkpoints", "last.ckpt")
+    sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
+    assert "model.MinkUNet.block5.0.conv1.kernel" in sd and int(sd["model.MinkUNet.bn0.bn.num_batches_tracked"]) == 12
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "predict.py"), "-w", ck, "--synthetic", "2",
+                        "-c", os.path.join(root, "config", "config.yaml")], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert any(l.startswith("dIoU .") for l in r.stdout.splitlines())

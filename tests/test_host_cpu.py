@@ -233,3 +233,30 @@ def test_reference_module_paths_and_map_loader(tmp_path, monkeypatch):
         util.load_point_cloud_map(None)
     with pytest.raises(RuntimeError, match="Failed to load point cloud map"):
         util.load_point_cloud_map({"TRAIN": {"MAP": "missing.npy"}})
+
+
+def test_augmentation_matches_reference_goldens():
+    """sps.datasets.augmentation + BacchusDataset(split="train", AUGMENTATION) under fixed torch seeds reproduce the clouds
+    the reference produced (tools/capture_goldens.py): same draws from torch's generator, same float32 arithmetic."""
+    import sps.datasets.augmentation as aug
+    import sps.datasets.blt_dataset as blt
+    z = np.load(os.path.join(GOLD, "augmentation.npz"))
+    pts = torch.from_numpy(z["pts"])
+    for seed in (0, 1, 7):
+        for name in ("rotate_point_cloud", "rotate_perturbation_point_cloud", "random_flip_point_cloud", "random_scale_point_cloud"):
+            torch.manual_seed(seed)
+            got = getattr(aug, name)(pts.clone()).numpy()
+            np.testing.assert_allclose(got, z[f"{name}_{seed}"], rtol=0, atol=2e-6, err_msg=f"{name} seed {seed}")
+    d = np.load(os.path.join(GOLD, "bacchus_dataset.npz"))
+    cfg = {"TRAIN": {"AUGMENTATION": True, "BATCH_SIZE": 1}, "MODEL": {"VOXEL_SIZE": 0.1}, "DATA": {"NUM_WORKER": 0, "SHUFFLE": False}}
+    for seed in (0, 1, 7):
+        torch.manual_seed(seed)
+        ds = blt.BacchusDataset(cfg, [d["scan0"], d["scan1"]], d["pc_map"], split="train")
+        item = ds[0].numpy()
+        want = z[f"item_aug_{seed}"]
+        assert item.shape == want.shape
+        np.testing.assert_allclose(item[:, :3], want[:, :3], rtol=0, atol=1e-5)
+        np.testing.assert_array_equal(item[:, 3:], want[:, 3:])                      # time stamp and label untouched
+    # no augmentation outside the training split
+    ds = blt.BacchusDataset(cfg, [d["scan0"]], d["pc_map"])
+    np.testing.assert_array_equal(ds[0].numpy(), d["item0"])

@@ -4,6 +4,7 @@
 
   sps.datasets.util.calculate_metrics / transform_point_cloud / inverse_transform_point_cloud
   sps.datasets.blt_dataset.BacchusDataset.__getitem__ / select_closest_points, BacchusModule.collate_fn
+  sps.datasets.augmentation.* and BacchusDataset.augment_data (training path)
 
 Third-party modules that are absent (rospy, ros_numpy, tf, sensor_msgs, MinkowskiEngine,
 pytorch_lightning, torchmetrics) are replaced by empty stubs: nothing that executes them is captured.
@@ -93,6 +94,21 @@ def main():
     batch = blt.BacchusModule.collate_fn(items)
     np.savez(os.path.join(OUT, "bacchus_dataset.npz"), pc_map=pc_map, scan0=scans[0], scan1=scans[1],
              item0=items[0].numpy(), item1=items[1].numpy(), batch=batch.numpy())
+    # ---- augmentation (augmentation.py:5-58; BacchusDataset.augment_data, blt_dataset.py:273-278) under fixed seeds
+    import sps.datasets.augmentation as aug
+    pts32 = torch.tensor(rng.uniform(-10, 10, size=(200, 3)), dtype=torch.float32)
+    out = {"pts": pts32.numpy()}
+    for seed in (0, 1, 7):
+        for name in ("rotate_point_cloud", "rotate_perturbation_point_cloud", "random_flip_point_cloud",
+                     "random_scale_point_cloud"):
+            torch.manual_seed(seed)
+            out[f"{name}_{seed}"] = getattr(aug, name)(pts32.clone()).numpy()
+        torch.manual_seed(seed)
+        cfg_aug = {"TRAIN": {"AUGMENTATION": True, "BATCH_SIZE": 1}, "MODEL": {"VOXEL_SIZE": 0.1},
+                   "DATA": {"NUM_WORKER": 0, "SHUFFLE": False}}
+        ds_aug = blt.BacchusDataset(cfg_aug, scans, pc_map, split="train")
+        out[f"item_aug_{seed}"] = ds_aug[0].numpy()
+    np.savez(os.path.join(OUT, "augmentation.npz"), **out)
     print("wrote", sorted(os.listdir(OUT)))
 
 
