@@ -373,16 +373,50 @@ def test_config3_batch4_streamed(net, params):
 
 
 @pytest.mark.timeout(900)
-def test_config4_nclt_size_properties(net, params):
-    """BASELINE config 4 (NCLT-like: 128 beams x 3600 azimuths to 100 m -> 528k rows, 224k active voxels): too big for a per-feature diff to be cheap, so check the
-    size-independent properties against the C oracle's scores + structural invariants."""
+def test_config3_batch4_full_size(net, params):
+    """BASELINE config 3 at spec size: four consecutive ~150k-row scans in one forward (collate_fn layout, ~600k rows)
+    against the C oracle: scores, labels, per-scan confusion counts; and batch independence at full size (every scan's
+    scores equal its single-scan forward to the rounding of a different tile composition)."""
     from oracle import c_oracle
-    sc = synthetic.make_scene(scan_seed=5, n_azimuth=3600, n_beams=128, max_range=100.0)
+    from sps_amd.models.models import metrics_from_sums
+    scans = [plant_threshold_labels(b) for b in synthetic.make_sequence(4)]
+    batch = synthetic.collate(scans)
+    assert len(batch) > 550_000 and sorted(np.unique(batch[:, 0])) == [0, 1, 2, 3]
+    dev = torch.from_numpy(batch).cuda()
+    s, sums = net.forward_metrics(dev, 4)
+    torch.cuda.synchronize()
+    sg, sums = s.cpu().numpy(), sums.cpu().numpy()
+    ref, info = c_oracle.forward(c_oracle.pack_blob(params), batch[:, :5], VS, nthreads=8)
+    assert ctx().level_counts() == info["level_counts"]
+    np.testing.assert_allclose(sg, ref, rtol=0, atol=1e-4)
+    e = np.float32(EPS)
+    band = np.abs(ref - e) > 1e-5
+    np.testing.assert_array_equal((sg < e)[band], (ref < e)[band])
+    off = 0
+    for b, scan in enumerate(scans):
+        rows = slice(off, off + len(scan))
+        off += len(scan)
+        assert_nondegenerate(sums[b])
+        np.testing.assert_array_equal(sums[b, 1:5], oracle_confusion(sg[rows], batch[rows]))
+        n_band = int((~band[rows] & (batch[rows, 4] == 1)).sum())
+        assert np.abs(sums[b, 1:5] - oracle_confusion(ref[rows], batch[rows])).max() <= n_band
+        single = net(torch.from_numpy(scan).cuda()).cpu().numpy()
+        np.testing.assert_allclose(sg[rows], single, rtol=0, atol=5e-6)
+        assert metrics_from_sums(sums[b])["dIoU"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_config4_nclt_size_properties(net, params):
+    """BASELINE config 4 at spec size (NCLT-like: three merged 128-beam scans to 100 m against a 25-position map ->
+    ~520k rows, >= 300k active level-0 voxels): too big for a per-feature diff to be cheap, so check the scores against
+    the C oracle plus size-independent structural invariants."""
+    from oracle import c_oracle
+    sc = synthetic.make_nclt_scene(seed=5)
     batch = sc["batch"]
     assert len(batch) > 500_000
     dev, s = run(net, batch)
     counts = ctx().level_counts()
-    assert counts[0] > 200_000 and all(counts[i] > counts[i + 1] > 0 for i in range(4))
+    assert counts[0] >= 300_000 and all(counts[i] > counts[i + 1] > 0 for i in range(4))
     blob = c_oracle.pack_blob(params)
     ref, info = c_oracle.forward(blob, batch[:, :5], VS, nthreads=8)
     assert counts == info["level_counts"]
