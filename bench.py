@@ -392,7 +392,10 @@ def main():
         "config": {"workload": workload, "baseline_config": args.config, "scans_per_step": nb,
                    "scan_points": n_scan, "rows": n_points, "voxels_per_level": V,
                    "pairs_3x3x3x3_per_level": pairs3, "pairs_5x5x5x1": pairs5, "sharding": f"dp{world}",
-                   "streams_per_gpu": S, "final_bias_calibrated": float(bias.item())},
+                   "streams_per_gpu": S, "final_bias_calibrated": float(bias.item()),
+                   "arena_mb_per_context": round(eng.ctxs[0].arena_bytes() / 2**20, 1),
+                   "arena_mb_all_contexts": round(sum(cx.arena_bytes() for cx in eng.ctxs) / 2**20, 1),
+                   "compact_arenas": eng.compact},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,
         "mean_confusion": confusion, "h2d_inclusive": h2d, "host_cores": os.cpu_count(),
     }

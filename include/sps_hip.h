@@ -31,7 +31,7 @@ extern "C" {
 #define SPS_OK 0
 #define SPS_ERR_INVALID (-1) /* bad argument / state                              */
 #define SPS_ERR_HIP (-2)     /* a HIP runtime call failed                        */
-#define SPS_ERR_NOMEM (-3)   /* device allocation failed                         */
+#define SPS_ERR_NOMEM (-3)   /* device allocation failed / compact arena overflow */
 #define SPS_ERR_RANGE (-4)   /* a coordinate does not fit the 64-bit voxel key   */
 #define SPS_ERR_NOWEIGHTS (-5)
 
@@ -59,6 +59,16 @@ int sps_ctx_destroy(sps_ctx *ctx);
 /* Pre-size the arena for clouds of up to max_points rows (optional: sps_forward grows it
  * on demand, which synchronises the device). */
 int sps_reserve(sps_ctx *ctx, int64_t max_points);
+/* Arena sizing.  By default every tensor stride ("level" l = 0..4, stride 2^l) can hold as many voxels as there are
+ * points: no input can overflow, at ~6.9 KB of device memory per point.  LiDAR clouds thin out quickly with the stride
+ * (V_l / V_0 ~ 0.39 / 0.14 / 0.05 / 0.015 at 0.1 m), so a streaming caller may give level l only frac[l] * max_points rows
+ * (frac[0] is ignored: level 0 always holds every point; blocks get half the rows' capacity): ~2.2 KB per point with
+ * {1, 0.6, 0.3, 0.15, 0.08}.  A forward whose cloud needs more is ABORTED on the device (its scores are NaN) and the next
+ * synchronising call (sps_check, sps_metrics) returns SPS_ERR_NOMEM after switching the context back to full-size
+ * arenas; the caller re-issues it.  frac = NULL restores the default.  Takes effect at the next reserve / forward
+ * (re-allocation: synchronises).  sps_arena_bytes: device bytes the context's arena holds. */
+int sps_ctx_set_level_fractions(sps_ctx *ctx, const float *frac);
+int64_t sps_arena_bytes(sps_ctx *ctx);
 
 /* ---- weights ------------------------------------------------------------------------
  * Replaces nn.Module.load_state_dict on CustomMinkUNet (reference scripts/predict.py:56-58,

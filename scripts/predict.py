@@ -105,15 +105,26 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    idx = []                                              # scan index of every used table row
-    with torch.no_grad():
-        for g, group in enumerate(batched(loader, batch_size)):
-            if g % world != rank:                         # parallel.shard_indices over groups
-                continue
-            batch = group[0] if len(group) == 1 else datasets.BacchusModule.collate_fn([b[:, 1:] for b in group])
-            eng.submit(batch, len(group))
-            idx += [g * batch_size + j for j in range(len(group))]
-    sums = eng.finish()
+    from sps_amd._native import ERR_NOMEM, SpsError
+    for attempt in (0, 1):
+        idx = []                                          # scan index of every used table row
+        eng.reset_table(n_scans + batch_size)
+        with torch.no_grad():
+            for g, group in enumerate(batched(loader, batch_size)):
+                if g % world != rank:                     # parallel.shard_indices over groups
+                    continue
+                batch = group[0] if len(group) == 1 else datasets.BacchusModule.collate_fn([b[:, 1:] for b in group])
+                eng.submit(batch, len(group))
+                idx += [g * batch_size + j for j in range(len(group))]
+        try:
+            sums = eng.finish()
+            break
+        except SpsError as e:
+            # a cloud whose coarse levels do not thin out like a LiDAR scan's outgrew the compact arenas (its forward was
+            # aborted): evaluate the sequence again on full-size arenas
+            if e.code != ERR_NOMEM or attempt:
+                raise
+            eng.use_full_arenas()
     n_local = len(idx)
     local_rows = torch.empty((n_local, parallel.ROW), dtype=torch.float64, device=dev)
     local_rows[:, 0] = torch.tensor(idx, dtype=torch.float64, device=dev)

@@ -12,6 +12,7 @@ from . import _build
 NUM_LEVELS = 5
 SPS_OK = 0
 ERR_RANGE = -4
+ERR_NOMEM = -3
 
 
 class SpsError(RuntimeError):
@@ -43,6 +44,8 @@ def _load() -> C.CDLL:
         "sps_ctx_create": (i32, [i32, C.POINTER(vp)]),
         "sps_ctx_destroy": (i32, [vp]),
         "sps_reserve": (i32, [vp, i64]),
+        "sps_ctx_set_level_fractions": (i32, [vp, vp]),
+        "sps_arena_bytes": (i64, [vp]),
         "sps_weights_num_tensors": (i32, []),
         "sps_weights_tensor_info": (i32, [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
         "sps_weights_numel": (i64, []),
@@ -98,6 +101,7 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
+           "sps_ctx_set_level_fractions", "sps_arena_bytes",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
            "sps_weights_create", "sps_weights_destroy", "sps_ctx_set_weights",
            "sps_forward", "sps_forward_metrics", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
@@ -174,6 +178,16 @@ class Context:
     # ---- thin wrappers ----------------------------------------------------------------
     def reserve(self, max_points: int):
         check(lib.sps_reserve(self.handle, int(max_points)))
+
+    LIDAR_FRACTIONS = (1.0, 0.6, 0.3, 0.15, 0.08)      # V_l / V_0 of 0.1 m LiDAR clouds is ~0.39 / 0.14 / 0.05 / 0.015
+
+    def set_level_fractions(self, frac=None):
+        """Compact arena (include/sps_hip.h): level l holds frac[l] * max_points rows; None = full size (never overflows)."""
+        arr = None if frac is None else (C.c_float * NUM_LEVELS)(*[float(x) for x in frac])
+        check(lib.sps_ctx_set_level_fractions(self.handle, arr))
+
+    def arena_bytes(self) -> int:
+        return int(lib.sps_arena_bytes(self.handle))
 
     def load_weights(self, blob_host_ptr: int, numel: int, out_channels: int = 1):
         check(lib.sps_weights_load_head(self.handle, blob_host_ptr, int(numel), int(out_channels)))

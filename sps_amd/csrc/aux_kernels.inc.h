@@ -19,7 +19,8 @@ struct MetricsArgs {
 // its rows changes (rows are grouped by b), so the 8 accumulators of a batch index see ~one atomic per workgroup.
 template <bool SLICE>
 __device__ inline void metrics_body(float *__restrict__ scores, const float *__restrict__ logits,
-                                    const int *__restrict__ inv, int n, const MetricsArgs m, int bid, int nb) {
+                                    const int *__restrict__ inv, int n, const MetricsArgs m, int bid, int nb,
+                                    bool aborted = false) {
   __shared__ double red[8][4];
   __shared__ int bsh[4];
   double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -33,7 +34,7 @@ __device__ inline void metrics_body(float *__restrict__ scores, const float *__r
   for (int p = bid * seg + (int)threadIdx.x; p < p_end; p += (int)blockDim.x) {
     float s;
     if (SLICE) {
-      const int vr = inv[p];
+      const int vr = aborted ? -1 : inv[p];
       s = vr >= 0 ? 1.0f / (1.0f + expf(-logits[vr])) : __builtin_nanf("");
       scores[p] = s;
     }
@@ -118,13 +119,14 @@ __global__ __launch_bounds__(256) void k_tail(const float *__restrict__ logits, 
     bhash_cleanup(pa, b / gb, b % gb, gb);
     return;
   }
+  const bool aborted = pa.counts[ABORT] != 0;
   if (m.acc) {
-    metrics_body<true>(scores, logits, inv, n, m, (int)blockIdx.x, gs);
+    metrics_body<true>(scores, logits, inv, n, m, (int)blockIdx.x, gs, aborted);
     return;
   }
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const int v = inv[p];
+  const int v = aborted ? -1 : inv[p];
   scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
 }
 

@@ -16,6 +16,8 @@ struct ConvArgs {
   const int *nbr;         // [K][ldn] or null (identity, K == 1)
   const uint32_t *tmask;  // [tiles][4] present-offset mask per 16-row tile, or null (K == 1)
   const int *n_out;       // device count of output rows
+  const int *abort_flag;  // counts[ABORT]: the forward was aborted (compact arena overflow), or null
+  int out_rows;           // k_upconv: row capacity of the FINE level it scatters into
   int64_t ldn;
   int ldi, ldo, ldr;
   int K, cin, cout, NT, upk;
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   __shared__ unsigned char klist[4][128];
   __shared__ uint32_t aoff_s[4][KCHUNK * 16];
   __shared__ uint32_t woff_s[4][KCHUNK];
+  if (a.abort_flag && *a.abort_flag) return;
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -375,6 +378,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 // row count, down table and down masks; a.out is the fine level's concat buffer.
 template <int NT>
 __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
+  if (a.abort_flag && *a.abort_flag) return;
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -409,6 +413,7 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
       for (int i = 0; i < 4; ++i) {
         const int ro = row0 + q * 4 + i;
         child[i] = ro < count ? a.nbr[(size_t)k * a.ldn + ro] : -1;
+        if (a.out_rows > 0 && child[i] >= a.out_rows) child[i] = -1;  // never scatter outside the fine level's arrays
       }
       floatx4 acc[NT];
 #pragma unroll
@@ -459,6 +464,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
                                                       const float *__restrict__ shift, float in_const,
                                                       float *__restrict__ out, int ldo, int relu) {
   __shared__ float w_s[128 * 8];
+  if (n_out[ABORT]) return;  // n_out = counts + 0
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
   const int n = *n_out;
@@ -564,6 +570,7 @@ __global__ void k_voxel_feat_accum(const float *__restrict__ feats, const int *_
 
 __global__ void k_voxel_feat_mean(const int *__restrict__ n_vox, const long long *__restrict__ vacc,
                                   const int *__restrict__ vcnt, float *__restrict__ vfeat) {
+  if (n_vox[ABORT]) return;
   const int n = *n_vox;
   for (int v = blockIdx.x * blockDim.x + threadIdx.x; v < n; v += gridDim.x * blockDim.x)
     vfeat[v] = (float)(((double)vacc[v] / FEAT_FIX) / (double)max(vcnt[v], 1));
@@ -580,6 +587,7 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
                                                      int ldo) {
   __shared__ float w_s[128 * 8];
   __shared__ float val_s[4][16][132];  // row stride 132: lane (r, q) reads bank 4r + q (+ 4g): conflict-free
+  if (n_out[ABORT]) return;  // n_out = counts + 0
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
   const int n = *n_out;
@@ -643,10 +651,10 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
 //   out[p, j] = act(sum_c F[inv[p], c] * W[c, j] + b[j]),  j < oc     (minkunet.py:152-158, :217-219)
 __global__ void k_slice_head(const float *__restrict__ F, int ldf, const int *__restrict__ inv, int n,
                              const float *__restrict__ W, const float *__restrict__ bias, int oc, int act,
-                             float *__restrict__ out, int64_t ldo) {
+                             float *__restrict__ out, int64_t ldo, const int *__restrict__ abort_flag) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const int v = inv[p];
+  const int v = (abort_flag && *abort_flag) ? -1 : inv[p];  // aborted forward: NaN
   float f[8];
   if (v >= 0) {
     const float4 a = *reinterpret_cast<const float4 *>(F + (size_t)v * ldf);
@@ -668,10 +676,10 @@ __global__ void k_slice_head(const float *__restrict__ F, int ldf, const int *__
 
 // slice (models.py:28) + sigmoid (models.py:29)
 __global__ void k_slice_sigmoid(const float *__restrict__ logits, const int *__restrict__ inv, int n,
-                                float *__restrict__ scores) {
+                                float *__restrict__ scores, const int *__restrict__ abort_flag) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const int v = inv[p];
+  const int v = (abort_flag && *abort_flag) ? -1 : inv[p];
   scores[p] = v >= 0 ? 1.0f / (1.0f + expf(-logits[v])) : __builtin_nanf("");
 }
 

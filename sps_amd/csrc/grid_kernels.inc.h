@@ -154,7 +154,13 @@ struct PyramidArgs {
   int *block_sums;    // scan scratch, `sums_stride` ints per level
   int sums_stride;
   const int *n_dev;   // null, or the device-side point count (<= the host-side bound the grids were sized for)
+  int capl[NLV], bcapl[NLV];  // row / block capacity of every level (compact arenas: smaller than the point capacity)
+  int *err;           // sticky error flags of the context: bit 0 coordinate range, bit 1 level capacity exceeded
 };
+
+// counts[ABORT]: set by the ranking kernels when a level needs more rows or blocks than its arrays hold; every later
+// kernel of the forward returns at once, the tail writes NaN scores and wipes the block hashes (sps_ctx compact mode)
+constexpr int ABORT = 15;
 
 // levels 1..4 in one pass: one thread per LEVEL-0 block inserts its ancestor block at every coarser
 // level (App. A.9: floor(c / 2ts) * 2ts applied l times = a right shift of the biased coordinate).
@@ -243,6 +249,7 @@ __device__ inline int2 block_exclusive_scan2(int v0, int v1, const int *__restri
 __global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(PyramidArgs a, int lv0, int n0) {
   __shared__ int lds[SCAN_BLOCK / 64];
   const int l = lv0 + blockIdx.y;
+  if (a.counts[ABORT]) return;
   const int n = l == 0 ? (a.n_dev ? min(n0, *a.n_dev) : n0) : a.counts[8];
   if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
   const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
@@ -267,6 +274,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv
   __shared__ int lds[SCAN_BLOCK / 64];
   __shared__ int2 wave_off[SCAN_BLOCK / 64];
   const int l = lv0 + blockIdx.y;
+  if (lv0 > 0 && a.counts[ABORT]) return;  // (level 0 ranks before anything can have overflowed)
   const int n = l == 0 ? (a.n_dev ? min(n0, *a.n_dev) : n0) : a.counts[8];
   const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
   if ((int)blockIdx.x >= nwg) return;  // counts were zeroed by the reset
@@ -282,7 +290,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv
     }
   }
   const int2 off = block_exclusive_scan2(flag, cnt, a.block_sums + l * a.sums_stride, lds, wave_off);
-  if (flag) {
+  if (flag && off.x < a.bcapl[l]) {
     const int r = off.x;
     a.h[l].rank[s] = r;
     a.bslot[l][r] = s;
@@ -296,6 +304,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv
   if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) {
     a.counts[8 + l] = off.x + flag;
     a.counts[l] = off.y + cnt;
+    if (off.x + flag > a.bcapl[l] || off.y + cnt > a.capl[l]) {  // this level does not fit its arrays: abort the forward
+      atomicOr(&a.counts[ABORT], 1);
+      atomicOr(a.err, 2);
+    }
   }
 }
 
@@ -307,6 +319,7 @@ __global__ __launch_bounds__(256) void k_rows_ancestors(const int *__restrict__ 
                                                          int n, BHash h, const int *__restrict__ bbase,
                                                          int *__restrict__ inv, int *__restrict__ vblock,
                                                          unsigned char *__restrict__ vbit, PyramidArgs a, int gp, int gb) {
+  if (a.counts[ABORT]) return;  // level 0 overflowed: ranks and row bases are incomplete
   if ((int)blockIdx.x >= gp) {
     const int b = (int)blockIdx.x - gp;
     blocks_to_ancestors(a, 1 + b / gb, b % gb, gb);
@@ -381,6 +394,7 @@ __device__ inline void link_levels(const PyramidArgs &a, int l, int bx, int nbx)
 // kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
 // One launch with link_levels (both only need the block ranks of all levels): workgroups [0, 4 * gb) link.
 __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1, int c2, int c3, int c4, int c5) {
+  if (a.counts[ABORT]) return;
   if ((int)blockIdx.x < 4 * gb) {
     link_levels(a, (int)blockIdx.x / gb, (int)blockIdx.x % gb, gb);
     return;
@@ -413,6 +427,16 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
 __device__ inline void bhash_cleanup(const PyramidArgs &a, int l, int bx, int nbx) {
   const int n = a.counts[8 + l];
   const BHash h = a.h[l];
+  if (a.counts[ABORT]) {  // the per-block slot list is incomplete: wipe the whole table (rare, self-healing)
+    const uint32_t slots = h.hmask + 1u;
+    for (uint32_t s = (uint32_t)bx * 256u + threadIdx.x; s < slots; s += (uint32_t)nbx * 256u) {
+      h.keys[s] = KEY_EMPTY;
+      h.mask[s] = 0ull;
+      h.first[s] = 0x7F7F7F7F;
+      if ((s & 31u) == 0u) h.occ[s >> 5] = 0u;
+    }
+    return;
+  }
   for (int r = bx * 256 + (int)threadIdx.x; r < n; r += nbx * 256) {
     const int s = a.bslot[l][r];
     h.keys[s] = KEY_EMPTY;

@@ -38,7 +38,7 @@ struct MapsArgs {
   uint32_t *tmdown[NLV];
   const int *counts;
   int chunk_off[NLV + 1];
-  int64_t ldn;
+  int64_t ldn[NLV];  // row stride of the level's tables (= its row capacity)
 };
 
 __device__ inline int level_of_chunk(const MapsArgs &a, int first_level, int &local, int bid) {
@@ -95,7 +95,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   const LevelView L = a.L[l];
   int *__restrict__ nbr = a.nbr3[l];
   uint32_t *__restrict__ tmask = a.tm3[l];
-  const int64_t ldn = a.ldn;
+  const int64_t ldn = a.ldn[l];
   const int lane = threadIdx.x & 63;
   const int nround = (n + 63) & ~63;  // whole waves take part in the ballots
   for (int u = local * 256 + (int)threadIdx.x; u < nround; u += nchunks * 256) {
@@ -203,7 +203,7 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
       const int cbit = ((((pz & 1) << 1) + dz) << 4) | ((((py & 1) << 1) + dy) << 2) | (((px & 1) << 1) + dx);
       int row = -1;
       if ((mk >> cbit) & 1ull) row = base + __popcll(mk & ((1ull << cbit) - 1ull));
-      if (ok) a.down[c][(size_t)k * a.ldn + u] = row;
+      if (ok) a.down[c][(size_t)k * a.ldn[c] + u] = row;
       const unsigned long long bal = __ballot(row >= 0);
       m |= ((bal >> (lane & 48)) & 0xFFFFull) != 0ull ? 1u << k : 0u;
     }
@@ -216,6 +216,7 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
 // (conv0, which also only needs the block structure, stays a launch of its own: merged in here it costs the map
 //  part two waves of occupancy and overlaps with nothing: 63 us merged vs 59 us apart)
 __global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int nchunk, int n_nbr) {
+  if (ma.counts[ABORT]) return;
   const int bid = (int)blockIdx.x;
   if (bid < n_nbr)
     build_nbr3(ma, bid % nchunk, bid / nchunk);

@@ -174,7 +174,15 @@ struct sps_ctx {
   int device = 0;
   sps_train *train = nullptr;
   int64_t cap = 0;       // arena capacity in rows (points)
-  int64_t hcap = 0;      // hash capacity
+  int64_t hcap = 0;      // hash capacity of level 0 (and of the submap scratch)
+  // per-level capacities: rows (voxels), blocks, hash slots.  Dense mode (default): every level can hold cap rows and
+  // blocks -- no forward can overflow.  Compact mode (sps_ctx_set_level_fractions): level l holds frac[l] * cap rows and
+  // half as many blocks; a forward that needs more sets a device flag, every later kernel of it exits, the scores are
+  // NaN and the next synchronising call reports SPS_ERR_NOMEM after switching the context back to dense sizes.
+  int64_t capl[SPS_NUM_LEVELS] = {}, bcapl[SPS_NUM_LEVELS] = {}, hcapl[SPS_NUM_LEVELS] = {};
+  int64_t hash_slots = 0;  // sum of hcapl
+  float lfrac[SPS_NUM_LEVELS] = {1.f, 1.f, 1.f, 1.f, 1.f};
+  bool compact = false, regrow = false;
   int64_t last_n = 0;    // points of the last forward
   bool have_weights = false;
   std::vector<void *> allocs;
@@ -251,51 +259,72 @@ void free_arena(sps_ctx *c) {
   } while (0)
 
 int reserve(sps_ctx *c, int64_t n) {
-  if (n <= c->cap) return SPS_OK;
+  if (n <= c->cap && !c->regrow) return SPS_OK;
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipDeviceSynchronize());
   // weights / small state survive: they are allocated separately in ctx_create / weights_load
+  if (n < c->cap) n = c->cap;
   free_arena(c);
+  c->regrow = false;
   const int64_t cap = ((n + 1023) / 1024) * 1024;
-  const int64_t hcap = next_pow2(2 * cap);
+  auto round1k = [](double v) { return (int64_t)((int64_t)(v + 1023.0) / 1024) * 1024; };
+  for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
+    const double f = (c->compact && l > 0) ? (double)c->lfrac[l] : 1.0;
+    c->capl[l] = std::max<int64_t>(1024, std::min<int64_t>(cap, round1k(f * (double)cap)));
+    c->bcapl[l] = c->compact ? std::max<int64_t>(1024, c->capl[l] / 2) : c->capl[l];
+  }
+  // level 0 hashes the points' blocks (<= n distinct keys): 2 cap slots never fill up.  Levels >= 1 hash ancestors of
+  // the level-0 blocks: at most bcapl[0] keys once the level-0 guard has passed
+  c->hcapl[0] = next_pow2(2 * cap);
+  for (int l = 1; l < SPS_NUM_LEVELS; ++l) c->hcapl[l] = c->compact ? next_pow2(2 * c->bcapl[0]) : c->hcapl[0];
+  const int64_t hcap = c->hcapl[0];
+  int64_t hslots = 0;
+  for (int l = 0; l < SPS_NUM_LEVELS; ++l) hslots += c->hcapl[l];
+  c->hash_slots = hslots;
   {
     // block hashes of all levels live in three allocations (one reset each when dirty)
     uint64_t *keys;
     unsigned long long *mask;
     int *first;
-    ALLOC(keys, uint64_t, hcap * SPS_NUM_LEVELS);
-    ALLOC(mask, unsigned long long, hcap * SPS_NUM_LEVELS);
-    ALLOC(first, int, hcap * SPS_NUM_LEVELS);
+    ALLOC(keys, uint64_t, hslots);
+    ALLOC(mask, unsigned long long, hslots);
+    ALLOC(first, int, hslots);
     uint32_t *occ;
-    ALLOC(occ, uint32_t, (hcap / 32) * SPS_NUM_LEVELS);
+    ALLOC(occ, uint32_t, hslots / 32);
     c->hash_occ_all = occ;
     c->hash_keys_all = keys;
     c->hash_mask_all = mask;
     c->hash_first_all = first;
+    int64_t hoff = 0;
     for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
       Level &L = c->lv[l];
-      L.h.keys = keys + (size_t)l * hcap;
-      L.h.mask = mask + (size_t)l * hcap;
-      L.h.first = first + (size_t)l * hcap;
-      ALLOC(L.h.rank, int, hcap);
-      L.h.occ = occ + (size_t)l * (hcap / 32);
-      L.h.hmask = (uint32_t)(hcap - 1);
-      ALLOC(L.bslot, int, cap);
-      ALLOC(L.bkey, uint64_t, cap);
-      ALLOC(L.bmask, unsigned long long, cap);
-      ALLOC(L.bbase, int, cap);
-      ALLOC(L.bparent, int, cap);
-      ALLOC(L.bchild, int, 8 * cap);
-      ALLOC(L.badj, int, 81 * cap);
-      ALLOC(L.vblock, int, cap);
-      ALLOC(L.vbit, unsigned char, cap);
-      ALLOC(L.sslot, int, cap);
+      const int64_t rows = c->capl[l], blocks = c->bcapl[l], hc = c->hcapl[l];
+      L.h.keys = keys + hoff;
+      L.h.mask = mask + hoff;
+      L.h.first = first + hoff;
+      ALLOC(L.h.rank, int, hc);
+      L.h.occ = occ + hoff / 32;
+      L.h.hmask = (uint32_t)(hc - 1);
+      hoff += hc;
+      ALLOC(L.bslot, int, blocks);
+      ALLOC(L.bkey, uint64_t, blocks);
+      ALLOC(L.bmask, unsigned long long, blocks);
+      ALLOC(L.bbase, int, blocks);
+      ALLOC(L.bparent, int, blocks);
+      ALLOC(L.bchild, int, 8 * blocks);
+      ALLOC(L.badj, int, 81 * blocks);
+      ALLOC(L.vblock, int, rows);
+      ALLOC(L.vbit, unsigned char, rows);
+      ALLOC(L.sslot, int, l == 0 ? cap : c->bcapl[0]);      // sources: points (level 0), level-0 blocks (levels >= 1)
       if (l == 0) ALLOC(L.sbit, unsigned char, cap);
-      ALLOC(L.inv, int, cap);
-      ALLOC(L.nbr3, int, 81 * cap);
+      ALLOC(L.inv, int, l == 0 ? cap : c->capl[l - 1]);     // point -> row (level 0); fine row -> parent row (levels >= 1)
+      ALLOC(L.nbr3, int, 81 * rows);
       if (l > 0) {
-        ALLOC(L.down, int, 8 * cap);
+        ALLOC(L.down, int, 8 * rows);
       }
+      // never-written entries must still be valid indices (stale reads in an aborted forward stay in range)
+      HIP_TRY(hipMemset(L.vblock, 0, sizeof(int) * (size_t)rows));
+      HIP_TRY(hipMemset(L.vbit, 0, (size_t)rows));
     }
     c->tables_dirty = true;
     ALLOC(c->sub.h.keys, uint64_t, hcap);
@@ -305,10 +334,14 @@ int reserve(sps_ctx *c, int64_t n) {
     ALLOC(c->sub.srckey, uint64_t, cap);
     ALLOC(c->sub.pslot, int, cap);
   }
+  size_t zr_words = 16;
   {
-    const size_t tm_words = (size_t)(cap / 16) * 4;  // cap is a multiple of 1024
+    auto tmw = [&](int l) { return (size_t)(c->capl[l] / 16) * 4; };  // capacities are multiples of 1024
+    zr_words += tmw(0);
+    for (int l = 1; l < SPS_NUM_LEVELS; ++l) zr_words += tmw(l);
+    for (int l = 0; l < SPS_NUM_LEVELS; ++l) zr_words += tmw(l);
     uint32_t *zr;
-    ALLOC(zr, uint32_t, 16 + tm_words * 14);
+    ALLOC(zr, uint32_t, zr_words);
     c->zero_region = zr;
     // zeroed at the start of every forward: the counters only.  Every tile-mask array behind them is overwritten
     // tile by tile by the forward that uses it (the 5x5x5 debug masks are cleared by their getter)
@@ -316,18 +349,19 @@ int reserve(sps_ctx *c, int64_t n) {
     c->counts = reinterpret_cast<int *>(zr);
     uint32_t *p = zr + 16;
     c->tm5 = p;
-    p += tm_words;
+    p += tmw(0);
     for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
       c->lv[l].tmdown = p;
-      p += tm_words;
+      p += tmw(l);
     }
     for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
       c->lv[l].tm3 = p;
-      p += tm_words;
+      p += tmw(l);
     }
   }
   ALLOC(c->block_sums, int, 2 * (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
   ALLOC(c->keep, int, cap);
+  const int64_t *cl = c->capl;
   ALLOC(c->cat8, float, 16 * cap);
   ALLOC(c->b8t, float, 8 * cap);
   ALLOC(c->b8o, float, 8 * cap);
@@ -335,34 +369,34 @@ int reserve(sps_ctx *c, int64_t n) {
   ALLOC(c->vacc, long long, cap);
   ALLOC(c->vcnt, int, cap);
   ALLOC(c->vfeat, float, cap);
-  ALLOC(c->x1, float, 8 * cap);
-  ALLOC(c->b1t, float, 8 * cap);
-  ALLOC(c->cat7, float, 24 * cap);
-  ALLOC(c->b7t, float, 16 * cap);
-  ALLOC(c->b7o, float, 16 * cap);
-  ALLOC(c->x2, float, 8 * cap);
-  ALLOC(c->b2t, float, 16 * cap);
-  ALLOC(c->cat6, float, 48 * cap);
-  ALLOC(c->b6t, float, 32 * cap);
-  ALLOC(c->b6o, float, 32 * cap);
-  ALLOC(c->x3, float, 16 * cap);
-  ALLOC(c->b3t, float, 32 * cap);
-  ALLOC(c->cat5, float, 96 * cap);
-  ALLOC(c->b5t, float, 64 * cap);
-  ALLOC(c->b5o, float, 64 * cap);
-  ALLOC(c->x4, float, 32 * cap);
-  ALLOC(c->b4t, float, 64 * cap);
-  ALLOC(c->b4o, float, 64 * cap);
+  ALLOC(c->x1, float, 8 * cl[1]);
+  ALLOC(c->b1t, float, 8 * cl[1]);
+  ALLOC(c->cat7, float, 24 * cl[1]);
+  ALLOC(c->b7t, float, 16 * cl[1]);
+  ALLOC(c->b7o, float, 16 * cl[1]);
+  ALLOC(c->x2, float, 8 * cl[2]);
+  ALLOC(c->b2t, float, 16 * cl[2]);
+  ALLOC(c->cat6, float, 48 * cl[2]);
+  ALLOC(c->b6t, float, 32 * cl[2]);
+  ALLOC(c->b6o, float, 32 * cl[2]);
+  ALLOC(c->x3, float, 16 * cl[3]);
+  ALLOC(c->b3t, float, 32 * cl[3]);
+  ALLOC(c->cat5, float, 96 * cl[3]);
+  ALLOC(c->b5t, float, 64 * cl[3]);
+  ALLOC(c->b5o, float, 64 * cl[3]);
+  ALLOC(c->x4, float, 32 * cl[4]);
+  ALLOC(c->b4t, float, 64 * cl[4]);
+  ALLOC(c->b4o, float, 64 * cl[4]);
   c->cap = cap;
   c->hcap = hcap;
   c->last_n = 0;
-  HIP_TRY(hipMemset(c->zero_region, 0, (16 + (size_t)(cap / 16) * 4 * 10) * sizeof(uint32_t)));  // counters + every mask word once
+  HIP_TRY(hipMemset(c->zero_region, 0, zr_words * sizeof(uint32_t)));  // counters + every mask word once
   // the block hashes start clean here (allocation time), not in the first forward: every later forward cleans up
   // after itself, so a context that was reserved up front issues no fill in its steady state
-  HIP_TRY(hipMemset(c->hash_keys_all, 0xFF, (size_t)hcap * SPS_NUM_LEVELS * sizeof(uint64_t)));
-  HIP_TRY(hipMemset(c->hash_mask_all, 0, (size_t)hcap * SPS_NUM_LEVELS * sizeof(unsigned long long)));
-  HIP_TRY(hipMemset(c->hash_first_all, 0x7F, (size_t)hcap * SPS_NUM_LEVELS * sizeof(int)));
-  HIP_TRY(hipMemset(c->hash_occ_all, 0, (size_t)(hcap / 32) * SPS_NUM_LEVELS * sizeof(uint32_t)));
+  HIP_TRY(hipMemset(c->hash_keys_all, 0xFF, (size_t)hslots * sizeof(uint64_t)));
+  HIP_TRY(hipMemset(c->hash_mask_all, 0, (size_t)hslots * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c->hash_first_all, 0x7F, (size_t)hslots * sizeof(int)));
+  HIP_TRY(hipMemset(c->hash_occ_all, 0, (size_t)(hslots / 32) * sizeof(uint32_t)));
   HIP_TRY(hipDeviceSynchronize());
   c->tables_dirty = false;
   return SPS_OK;
@@ -395,6 +429,11 @@ PyramidArgs pyramid_args(sps_ctx *c) {
   a.block_sums = c->block_sums;
   a.sums_stride = (int)(2 * (c->cap / SCAN_BLOCK + 8));
   a.n_dev = nullptr;
+  for (int l = 0; l < NLV; ++l) {
+    a.capl[l] = (int)c->capl[l];
+    a.bcapl[l] = (int)c->bcapl[l];
+  }
+  a.err = c->err;
   return a;
 }
 
@@ -474,8 +513,9 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.ldr = cc.ldr;
   a.nbr = cc.map.nbr;
   a.tmask = cc.map.tmask;
-  a.ldn = c->cap;
+  a.ldn = c->capl[cc.level_out];
   a.n_out = c->counts + cc.level_out;
+  a.abort_flag = c->counts + 15;
   a.K = cs.K;
   a.cin = cs.cin;
   a.cout = cs.cout;
@@ -501,7 +541,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.in2 = cc.in2;
   a.ldi2 = cc.ldi2;
   a.upk2 = cs.ds_cin / 4;
-  a.in2_bytes = (uint32_t)((size_t)c->cap * (size_t)(cc.ldi2 > 0 ? cc.ldi2 : 1) * 4u);
+  a.in2_bytes = (uint32_t)((size_t)c->capl[cc.level_out] * (size_t)(cc.ldi2 > 0 ? cc.ldi2 : 1) * 4u);
   if (cs.ds_cin > 0 && !cc.in2) return fail(SPS_ERR_INVALID, "%s needs the block input for its fused downsample", cc.name);
   if (cc.fin) {
     const ConvSpec &fs = s.convs[s.find_conv("final")];
@@ -509,10 +549,13 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     a.fin_b = c->final_bias;
     a.fin_out = c->logits;
   }
-  a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)cc.ldi * 4u);
+  // level of the input rows: the level itself (3^4, 1x1), the finer one (stride-2 conv), the coarser one (transposed)
+  const bool is_up = cs.K == 8 && std::strncmp(cc.name, "convtr", 6) == 0;
+  const int level_in = cs.K == 8 ? (is_up ? cc.level_out + 1 : cc.level_out - 1) : cc.level_out;
+  a.in_bytes = (uint32_t)((size_t)c->capl[level_in < 0 ? 0 : level_in] * (size_t)cc.ldi * 4u);
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
-  a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->cap * 4u);
-  a.tile_cap = (int)(c->cap / 16);
+  a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->capl[cc.level_out] * 4u);
+  a.tile_cap = (int)(c->capl[cc.level_out] / 16);
   {
     static const char *trace_layer = getenv("SPS_TRACE_LAYER");  // diagnostic builds (-DSPS_WAVE_TRACE) only
     a.trace_on = trace_layer && std::strcmp(trace_layer, cc.name) == 0;
@@ -534,6 +577,9 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       a.nbr = c->lv[coarse].down;
       a.tmask = c->lv[coarse].tmdown;
       a.n_out = c->counts + coarse;
+      a.ldn = c->capl[coarse];
+      a.tile_cap = (int)(c->capl[coarse] / 16);
+      a.out_rows = (int)c->capl[cc.level_out];
       int64_t gu = (c->cap / 16) >> coarse;  // one workgroup per 16 parent rows
       if (gu < 64) gu = 64;
       if (gu > 8192) gu = 8192;
@@ -914,7 +960,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points (limit %d)", SPS_MAX_POINTS);
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
-  if (n > c->cap) {
+  if (n > c->cap || c->regrow) {
     int rc = reserve(c, n);
     if (rc != SPS_OK) return rc;
   }
@@ -937,10 +983,10 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   if (!skip_front) {
   // ---- reset: the block hashes are cleaned by the previous forward; full reset only when dirty
   if (c->tables_dirty) {
-    HIP_TRY(hipMemsetAsync(c->hash_keys_all, 0xFF, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(uint64_t), st));
-    HIP_TRY(hipMemsetAsync(c->hash_mask_all, 0, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(unsigned long long), st));
-    HIP_TRY(hipMemsetAsync(c->hash_first_all, 0x7F, (size_t)c->hcap * SPS_NUM_LEVELS * sizeof(int), st));
-    HIP_TRY(hipMemsetAsync(c->hash_occ_all, 0, (size_t)(c->hcap / 32) * SPS_NUM_LEVELS * sizeof(uint32_t), st));
+    HIP_TRY(hipMemsetAsync(c->hash_keys_all, 0xFF, (size_t)c->hash_slots * sizeof(uint64_t), st));
+    HIP_TRY(hipMemsetAsync(c->hash_mask_all, 0, (size_t)c->hash_slots * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(c->hash_first_all, 0x7F, (size_t)c->hash_slots * sizeof(int), st));
+    HIP_TRY(hipMemsetAsync(c->hash_occ_all, 0, (size_t)(c->hash_slots / 32) * sizeof(uint32_t), st));
   }
   if (c->tables_dirty) HIP_TRY(hipMemsetAsync(c->zero_region, 0, c->zero_bytes, st));
   c->tables_dirty = true;
@@ -1012,7 +1058,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   }
   ma.chunk_off[NLV] = off;
   ma.counts = c->counts;
-  ma.ldn = cap;
+  for (int l = 0; l < NLV; ++l) ma.ldn[l] = c->capl[l];
   // (the 5x5x5x1 map is never materialised: conv0 is fused with it, k_conv0_fused)
   if (no_merge & 4) {
     hipLaunchKernelGGL(k_maps, dim3(off * 3), dim3(256), 0, st, ma, off, off * 3);
@@ -1070,11 +1116,11 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     const NetSpec &s = *c->net;
     const ConvSpec &fs = s.convs[s.find_conv("final")];
     hipLaunchKernelGGL(k_slice_head, dim3((unsigned)gs), dim3(256), 0, st, c->b8o, 8, L0.inv, (int)n,
-                       c->blob + fs.w_off, c->blob + s.bias_off, s.out_channels, fo.act, scores, fo.ldo);
+                       c->blob + fs.w_off, c->blob + s.bias_off, s.out_channels, fo.act, scores, fo.ldo, c->counts + 15);
     prof_mark(c, "slice_head", st);
     if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
   } else if (skip_front || (no_merge & 8)) {
-    hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)gs), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores);
+    hipLaunchKernelGGL(k_slice_sigmoid, dim3((unsigned)gs), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores, c->counts + 15);
     if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
     if (fo.metrics_out) {  // diagnostics paths: the unfused sequence
       HIP_TRY(hipMemsetAsync(fo.metrics_out, 0, (size_t)fo.n_batches * 8 * sizeof(double), st));
@@ -1125,6 +1171,23 @@ int sps_profile_read(sps_ctx *c, int idx, char *name, int name_cap, float *ms) {
   return SPS_OK;
 }
 
+// sticky device error flags -> error code (after the caller has synchronised the stream that copied them)
+static int report_device_errors(sps_ctx *c, int e, hipStream_t st) {
+  if (!e) return SPS_OK;
+  HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), st));
+  if (e & 2) {
+    // a level outgrew its compact arrays: that forward was aborted (NaN scores).  Dense sizes from now on -- the next
+    // forward re-allocates and cannot overflow; the caller re-issues the affected work
+    c->compact = false;
+    c->regrow = true;
+    return fail(SPS_ERR_NOMEM, "a coarse level needed more rows or blocks than the compact arena holds (set by "
+                               "sps_ctx_set_level_fractions): the forward was aborted and its scores are NaN; the context "
+                               "has switched to full-size arenas, re-issue the forward");
+  }
+  return fail(SPS_ERR_RANGE,
+              "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");
+}
+
 int sps_check(sps_ctx *c, void *stream) {
   if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
   HIP_TRY(hipSetDevice(c->device));
@@ -1132,12 +1195,38 @@ int sps_check(sps_ctx *c, void *stream) {
   int e = 0;
   HIP_TRY(hipMemcpyAsync(&e, c->err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (e) {
-    HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), st));
-    return fail(SPS_ERR_RANGE,
-                "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");
+  return report_device_errors(c, e, st);
+}
+
+int sps_ctx_set_level_fractions(sps_ctx *c, const float *frac) {
+  if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
+  bool compact = false;
+  float f[SPS_NUM_LEVELS] = {1.f, 1.f, 1.f, 1.f, 1.f};
+  if (frac) {
+    for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
+      if (!(frac[l] > 0.f && frac[l] <= 1.f)) return fail(SPS_ERR_INVALID, "level fractions must be in (0, 1]");
+      f[l] = frac[l];
+      compact = compact || frac[l] < 1.f;
+    }
+  }
+  if (compact != c->compact || std::memcmp(f, c->lfrac, sizeof f) != 0) {
+    std::memcpy(c->lfrac, f, sizeof f);
+    c->compact = compact;
+    if (c->cap > 0) c->regrow = true;  // applied by the next reserve / forward
   }
   return SPS_OK;
+}
+
+int64_t sps_arena_bytes(sps_ctx *c) {
+  if (!c) return 0;
+  HIP_TRY(hipSetDevice(c->device));
+  int64_t total = 0;
+  for (void *p : c->allocs) {
+    size_t sz = 0;
+    void *base = nullptr;
+    if (hipMemGetAddressRange(&base, &sz, p) == hipSuccess) total += (int64_t)sz;
+  }
+  return total;
 }
 
 int sps_metrics(sps_ctx *c, const float *scores, const float *batch, int64_t ld, int64_t n, float eps, int n_batches,
@@ -1155,11 +1244,7 @@ int sps_metrics(sps_ctx *c, const float *scores, const float *batch, int64_t ld,
   int e = 0;
   HIP_TRY(hipMemcpyAsync(&e, c->err, sizeof(int), hipMemcpyDeviceToHost, st));
   HIP_TRY(hipStreamSynchronize(st));
-  if (e) {
-    HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), st));
-    return fail(SPS_ERR_RANGE, "a coordinate is outside the voxel-key range");
-  }
-  return SPS_OK;
+  return report_device_errors(c, e, st);
 }
 
 static int map_upload_impl(sps_ctx *c, const void *src, bool ijk, int64_t ld, int64_t m, float ds, void *stream) {
@@ -1463,7 +1548,8 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
     hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0,
                        c->lv[0].view(), c->nbr5, c->cap, c->tm5);
   HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
-  hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, c->cap, which == 5 ? 0 : 1,
+  hipLaunchKernelGGL(k_count_pairs, dim3(grid_for(c->cap, 256, 1024), K), dim3(256), 0, 0, nbr, which == 5 ? c->cap : c->capl[level],
+                     which == 5 ? 0 : 1,
                      c->counts + level, which == 5 ? c->tm5 : c->lv[which].tm3, c->pairs);
   unsigned long long h[128];
   HIP_TRY(hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost));
@@ -1490,7 +1576,7 @@ int sps_get_nbr(sps_ctx *c, int which, int32_t *nbr_dev) {
   int rc = sps_level_counts(c, cnt);
   if (rc != SPS_OK) return rc;
   for (int k = 0; k < 81; ++k)
-    HIP_TRY(hipMemcpy(nbr_dev + (size_t)k * cnt[which], c->lv[which].nbr3 + (size_t)k * c->cap,
+    HIP_TRY(hipMemcpy(nbr_dev + (size_t)k * cnt[which], c->lv[which].nbr3 + (size_t)k * c->capl[which],
                       (size_t)cnt[which] * sizeof(int), hipMemcpyDeviceToDevice));
   return SPS_OK;
 }

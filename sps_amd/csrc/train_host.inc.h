@@ -241,7 +241,9 @@ int conv_plain(sps_ctx *c, hipStream_t st, TKind gather, int level_rows, int K, 
   a.shift = t->zeros;
   a.res = accumulate ? out : nullptr;
   a.ldr = ldo;
-  a.ldn = c->cap;
+  a.ldn = c->capl[level_rows];
+  a.abort_flag = nullptr;
+  a.out_rows = 0;
   a.K = K;
   a.cin = cin;
   a.cout = cout;
@@ -251,10 +253,10 @@ int conv_plain(sps_ctx *c, hipStream_t st, TKind gather, int level_rows, int K, 
   a.relu = 0;
   a.in_const = 0.5f;
   a.S = 1;
-  a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)ldi * 4u);
+  a.in_bytes = (uint32_t)((size_t)c->cap * (size_t)ldi * 4u);  // training runs on dense arenas: every level holds cap rows
   a.wu_bytes = (uint32_t)((size_t)K * a.upk * a.NT * 64 * 4);
-  a.nbr_bytes = (uint32_t)((size_t)K * (size_t)c->cap * 4u);
-  a.tile_cap = (int)(c->cap / 16);
+  a.nbr_bytes = (uint32_t)((size_t)K * (size_t)c->capl[level_rows] * 4u);
+  a.tile_cap = (int)(c->capl[level_rows] / 16);
   a.n_out = c->counts + level_rows;
   Level &L = c->lv[level_rows];
   if (gather == T_UP) {
@@ -299,7 +301,7 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
   w.cout = cout;
   w.MT = (cin + 15) / 16;
   w.NT = (cout + 15) / 16;
-  w.ldn = c->cap;
+  w.ldn = c->capl[level_rows];
   w.n_rows = c->counts + level_rows;
   w.slab = t->slab;
   Level &L = c->lv[level_rows];
@@ -333,6 +335,10 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
   if (numel != s.numel) return fail(SPS_ERR_INVALID, "parameter blob has %lld floats, expected %lld", (long long)numel, (long long)s.numel);
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
+  if (c->compact) {  // the backward indexes every level's arrays on the host's assumption that nothing was aborted
+    c->compact = false;
+    if (c->cap > 0) c->regrow = true;
+  }
   // coordinate structures: the inference front-end with the network skipped (weights are not needed for it)
   {
     ForwardOpts fo;
@@ -395,7 +401,7 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
   // final 1x1 conv + bias, slice, sigmoid (models.py:28-29)
   const ConvSpec &fs = s.convs[s.find_conv("final")];
   hipLaunchKernelGGL(k_slice_head, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->b8o, 8, c->lv[0].inv, (int)n,
-                     t->blob + fs.w_off, t->blob + s.bias_off, 1, 1, scores, (int64_t)1);
+                     t->blob + fs.w_off, t->blob + s.bias_off, 1, 1, scores, (int64_t)1, (const int *)nullptr);
   if (batch_stats_dev)
     HIP_TRY(hipMemcpyAsync(batch_stats_dev, t->batch_stats, (size_t)s.ss_numel * sizeof(float), hipMemcpyDeviceToDevice, st));
   // the block hashes go back to "free" (the inference forward does this in its tail kernel)

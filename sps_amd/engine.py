@@ -25,7 +25,7 @@ DEFAULT_STREAMS = 23      # the HIP runtime multiplexes streams onto 4 hardware 
 
 class ScanEngine:
     def __init__(self, net: SPSNet, device: torch.device | int | None = None, streams: int = DEFAULT_STREAMS,
-                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0):
+                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0, compact: bool = True):
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
@@ -38,6 +38,13 @@ class ScanEngine:
             self.main = torch.cuda.current_stream()
             self.streams = [torch.cuda.Stream(device=self.device) for _ in range(S)] if S > 1 else [self.main]
             self.ctxs = [get_context(self.index, st.cuda_stream) for st in self.streams]
+        # LiDAR-sized arenas (2.2 KB instead of 6.9 KB of device memory per point and context): a cloud whose coarse
+        # levels do not thin out like a LiDAR scan's aborts its forward on the device; finish() then raises SpsError
+        # (SPS_ERR_NOMEM) with the contexts already switched to full-size arenas, and run_sequence() re-runs once
+        self.compact = bool(compact)
+        if self.compact:
+            for cx in self.ctxs:
+                cx.set_level_fractions(cx.LIDAR_FRACTIONS)
         self._next = 0
         self._stage = [None] * S          # per-stream device staging buffer for host batches
         self._pinned = [None] * S
@@ -116,6 +123,12 @@ class ScanEngine:
         dst.copy_(host, non_blocking=True)
         return dst
 
+    def use_full_arenas(self) -> None:
+        """Every context back to full-size arenas (cannot overflow; re-allocated by the next forward)."""
+        self.compact = False
+        for cx in self.ctxs:
+            cx.set_level_fractions(None)
+
     def finish(self) -> torch.Tensor:
         """The one synchronisation of a sequence: drains every stream, raises on sticky device errors, returns the
         used part of the metric table (device tensor [rows, 8])."""
@@ -123,18 +136,33 @@ class ScanEngine:
             for st in self.streams:
                 if st is not self.main:
                     self.main.wait_stream(st)
+            first = None
             for cx, st in zip(self.ctxs, self.streams):
-                cx.check_errors(st.cuda_stream)            # synchronises the stream
+                try:
+                    cx.check_errors(st.cuda_stream)        # synchronises the stream
+                except Exception as e:                     # keep draining: every context must see its own flag
+                    first = first or e
+            if first is not None:
+                raise first
         return self.table[: self.rows_used] if self.table is not None else None
 
     # ---- whole sequences ---------------------------------------------------------------------------------------------
     def run_sequence(self, batches, n_batches: int = 1) -> np.ndarray:
         """All batches of a sequence through the pipeline; returns the per-scan metric sums [len * n_batches, 8]."""
+        from ._native import ERR_NOMEM, SpsError
         batches = list(batches)
-        self.reset_table(len(batches) * n_batches)
-        for b in batches:
-            self.submit(b, n_batches)
-        return self.finish().cpu().numpy()
+        for attempt in (0, 1):
+            self.reset_table(len(batches) * n_batches)
+            for b in batches:
+                self.submit(b, n_batches)
+            try:
+                return self.finish().cpu().numpy()
+            except SpsError as e:
+                if e.code != ERR_NOMEM or attempt:
+                    raise
+                # some cloud outgrew the compact arenas: this is not LiDAR-like data -- every context goes back to
+                # full-size arenas (which cannot overflow) and the sequence runs again
+                self.use_full_arenas()
 
 
 def per_scan_metrics(sums: np.ndarray) -> list[dict]:

@@ -164,7 +164,8 @@ def test_scan_engine_matches_per_scan_predict_step(net, params):
     want = []
     for b in scans:
         want.append(net.predict_step(torch.from_numpy(b).cuda(), 0))
-    eng = ScanEngine(net, 0, streams=4, max_rows=max(len(b) for b in scans), table_rows=len(scans))
+    # (the small random test scenes are not LiDAR-like: full-size arenas; the compact ones have their own test below)
+    eng = ScanEngine(net, 0, streams=4, max_rows=max(len(b) for b in scans), table_rows=len(scans), compact=False)
     feeds = {"device": [torch.from_numpy(b).cuda() for b in scans],
              "pinned": [torch.from_numpy(b).pin_memory() for b in scans],
              "pageable": [torch.from_numpy(b) for b in scans]}
@@ -243,3 +244,56 @@ def test_predict_cli_pipelined_matches_bench_loop():
         assert "timing:" in lines, r.stdout
         outs.append([lines[k] for k in ("Loss", "R2", "dIoU", "Precision", "Recall", "F1")])
     assert outs[0] == outs[1]
+
+
+def test_compact_arena_overflow_aborts_reports_and_recovers(net, params):
+    """sps_ctx_set_level_fractions: LiDAR-sized level arrays.  A LiDAR-like cloud runs unchanged in a third of the memory;
+    a cloud whose coarse levels do not thin out (every point its own voxel at every stride) makes its forward abort on the
+    device: NaN scores, SPS_ERR_NOMEM at the next synchronising call, full-size arenas afterwards; the block hashes are
+    left clean (the following forwards are bit-identical to a fresh context's)."""
+    from sps_amd import _native
+    from sps_amd._native import SpsError
+    lidar = synthetic.make_scene(scan_seed=21, n_azimuth=500)["batch"]
+    rng = np.random.default_rng(4)
+    sparse = np.zeros((len(lidar), 6), np.float32)
+    sparse[:, 1:4] = rng.uniform(-400, 400, (len(lidar), 3))         # ~one point per 0.1 m voxel AND per 1.6 m voxel
+    sparse[:, 4] = rng.integers(0, 2, len(lidar))
+    dense_ctx = ctx()
+    net.model._sync_weights(dense_ctx)
+    want_lidar = net(torch.from_numpy(lidar).cuda()).cpu().numpy()
+    want_sparse = net(torch.from_numpy(sparse).cuda()).cpu().numpy()
+    assert np.isfinite(want_sparse).all()
+    dense_bytes = None
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        from sps_amd.models.models import get_context
+        c = get_context(0, st.cuda_stream)
+        c.reserve(len(lidar))
+        dense_bytes = c.arena_bytes()
+        c.set_level_fractions(c.LIDAR_FRACTIONS)
+        c.reserve(len(lidar))
+        compact_bytes = c.arena_bytes()
+        assert compact_bytes < 0.4 * dense_bytes, (compact_bytes, dense_bytes)
+        got = net(torch.from_numpy(lidar).cuda())
+        c.check_errors(st.cuda_stream)
+        np.testing.assert_array_equal(got.cpu().numpy(), want_lidar)                 # same bits in a third of the memory
+        bad = net(torch.from_numpy(sparse).cuda())
+        with pytest.raises(SpsError) as ei:
+            c.check_errors(st.cuda_stream)
+        assert ei.value.code == _native.ERR_NOMEM
+        assert torch.isnan(bad).all()                                               # the aborted forward: no stale scores
+        again = net(torch.from_numpy(sparse).cuda())                                # full-size arenas now
+        c.check_errors(st.cuda_stream)
+        np.testing.assert_array_equal(again.cpu().numpy(), want_sparse)
+        assert c.arena_bytes() >= dense_bytes
+        np.testing.assert_array_equal(net(torch.from_numpy(lidar).cuda()).cpu().numpy(), want_lidar)   # hashes were left clean
+        c.check_errors(st.cuda_stream)
+    # the engine's sequence loop retries by itself
+    from sps_amd.engine import ScanEngine
+    eng = ScanEngine(net, 0, streams=2, max_rows=len(lidar))
+    assert eng.compact
+    sums = eng.run_sequence([torch.from_numpy(b).cuda() for b in (lidar, sparse, lidar)])
+    assert sums.shape == (3, 8) and np.isfinite(sums).all() and sums[0, 0] == (lidar[:, 4] == 1).sum()
+    np.testing.assert_array_equal(sums[0, :5], sums[2, :5])
+    np.testing.assert_allclose(sums[0, 5:], sums[2, 5:], rtol=1e-12)     # f64 atomics: order-dependent rounding
+    assert not eng.compact                                           # fell back to full-size arenas
