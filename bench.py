@@ -216,6 +216,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    issue_s = [0.0]
+
     def timed_region(feed):
         """W untimed + exactly K timed steps; returns (wall seconds incl. the metric all-gather, GPU ms first start ->
         last end over all launch streams, gathered rows or None, scores of the last step)."""
@@ -233,6 +235,7 @@ def main():
         scores = None
         for i in range(K):
             scores = eng.submit(feed[i % len(feed)], nb, row=i * nb)
+        issue_s[0] = time.perf_counter() - t0          # host time to issue the K steps (no synchronisation inside)
         for st, e in zip(streams, ev1):
             e.record(st)
         gathered = None
@@ -251,6 +254,7 @@ def main():
         return float(el.item()), gpu_ms, gathered, scores
 
     elapsed, gpu_ms, gathered, scores = timed_region(batches)
+    host_issue_ms = issue_s[0] / K * 1e3
     rows_resident = (torch.cat(gathered, 0) if gathered is not None else eng.table[: K * nb]).cpu().numpy().copy()
     h2d = None
     if not args.no_h2d:
@@ -398,6 +402,7 @@ def main():
                    "compact_arenas": eng.compact},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,
         "mean_confusion": confusion, "h2d_inclusive": h2d, "host_cores": os.cpu_count(),
+        "host_issue_ms_per_step": round(host_issue_ms, 4),
     }
     print(json.dumps(out))
     if dist is not None:

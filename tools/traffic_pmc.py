@@ -3,7 +3,19 @@ MI355X_MICROARCH.md section HBM: separate passes; FETCH_SIZE/WRITE_SIZE are in K
 FETCH_SIZE reports 1/2 of the bytes of wide coalesced streaming reads -> the read side is DOUBLED
 (upper estimate: our gathers are narrower than 16 B/lane streams, for which the factor is uncalibrated).
 Usage: traffic_pmc.py <fetch_dir> <write_dir> <out.json>"""
-import csv, glob, json, sys, collections
+import csv, glob, hashlib, json, os, sys, collections
+
+
+def csrc_sha():
+    """Same hash as bench.py: the traffic figure is only reported for the build of the kernels it was measured with."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "sps_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".inc.h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 def per_scan(d, counter):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]
@@ -19,7 +31,7 @@ def per_scan(d, counter):
 fetch = per_scan(sys.argv[1], "FETCH_SIZE")
 write = per_scan(sys.argv[2], "WRITE_SIZE")
 kib_f, kib_w = sum(fetch.values()), sum(write.values())
-out = {"fetch_size_kib_raw": kib_f, "write_size_kib": kib_w,
+out = {"csrc_sha": csrc_sha(), "fetch_size_kib_raw": kib_f, "write_size_kib": kib_w,
        "hbm_bytes_per_scan": int((2 * kib_f + kib_w) * 1024),
        "hbm_bytes_per_scan_uncorrected": int((kib_f + kib_w) * 1024),
        "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over bench.py --streams 1; "
