@@ -13,5 +13,5 @@ for ln in lines[1:]:
     cyc = v["GRBM_GUI_ACTIVE"] / 8
     mf = v["_VALU_MFMA_BUSY_CYCLES"] / 1024 / cyc
     ta = v["TA_TA_BUSY_sum"] / 256 / cyc
-    miss = v["TCP_TCC_READ_REQ_sum"] / max(v["TAL_CACHE_ACCESSES_sum"], 1)
+    miss = v["TCP_TCC_READ_REQ_sum"] / max(v["TAL_CACHE_ACCESSES_sum"], 1) if "TAL_CACHE_ACCESSES_sum" in v else float("nan")
     print(f"{p[0]:16s} {cyc/1e3:8.1f} {cyc/2400:9.1f} {int(v['SQ_INSTS_MFMA']):10d} {mf:9.1%} {ta:8.1%} {miss:11.2f}")

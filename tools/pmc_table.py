@@ -4,8 +4,9 @@ import csv, glob, sys, collections
 sys.path.insert(0, ".")
 names = ["conv1p1s2", "block1.conv1", "block1.conv2", "conv2p2s2", "block2.conv1", "block2.conv2",
          "conv3p4s2", "block3.conv1", "block3.conv2", "conv4p8s2", "block4.conv1", "block4.conv2",
-         "convtr4", "block5.conv1", "block5.conv2", "convtr5", "block6.conv1", "block6.conv2",
-         "convtr6", "block7.conv1", "block7.conv2", "convtr7", "block8.conv1", "block8.conv2"]
+         "block5.conv1", "block5.conv2", "block6.conv1", "block6.conv2",
+         "block7.conv1", "block7.conv2", "block8.conv1", "block8.conv2"]       # k_conv launches in forward order
+up_names = ["convtr4", "convtr5", "convtr6", "convtr7"]                        # k_upconv launches
 table = collections.defaultdict(lambda: collections.defaultdict(list))
 other = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
@@ -14,12 +15,19 @@ for d in sys.argv[1:]:
     by_disp = collections.OrderedDict()
     for r in rows:
         by_disp.setdefault(int(r["Dispatch_Id"]), []).append(r)
-    conv_i = -1
+    conv_i = up_i = -1
     for did in sorted(by_disp):
         rs = by_disp[did]
         kn = rs[0]["Kernel_Name"]
         if "k_points_to_blocks" in kn:
             conv_i = -1
+            up_i = -1
+        if "k_upconv<" in kn:
+            up_i += 1
+            key = up_names[up_i] if 0 <= up_i < len(up_names) else f"up{up_i}"
+            for r in rs:
+                table[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            continue
         if "k_conv<" in kn:
             conv_i += 1
             key = names[conv_i] if 0 <= conv_i < len(names) else f"conv{conv_i}"
@@ -35,6 +43,6 @@ def show(tab, order):
     for k in order:
         if k not in tab: continue
         print(k.ljust(20) + "".join(f"{sum(tab[k][c]) / max(len(tab[k][c]), 1):24.0f}" if c in tab[k] else " " * 24 for c in ctrs))
-show(table, names)
+show(table, names + up_names)
 print()
 show(other, sorted(other))
