@@ -368,173 +368,6 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 #endif
 }
 
-// Weights in LDS (NT = 1 layers, S = 1): a 896- or 1024-thread workgroup stages the layer's whole unit-major weight set once
-// (20-83 KB; only the cout <= 8 or 16 real columns) and its 14 / 16 waves then run the k_conv tile loop with the B fragment of
-// every unit group coming from LDS (ds_read_b128, conflict-free: the four lane groups read four 128/256-byte runs) instead
-// of the texture path.  What that buys: (i) the texture path carries only the gathered A operands (the weight loads were
-// half of its instructions and a third of its busy time, profiles/round1_r1c/pmc_conv_layers_derived.txt); (ii) the
-// registers the weight fragments of G groups held are free, so a wave keeps more gathers in flight per dependent round
-// trip (the fine-level waves are latency chains: their lifetime is round trips x latency).  Same per-element MFMA sequence
-// as k_conv<1, ., ., DS, FIN, 1>: bit-identical results.
-constexpr int LKCHUNK = 32;
-template <int NW, int G, int MINW, bool DS, bool FIN>
-__global__ __launch_bounds__(NW * 64, MINW) void k_conv_lds(ConvArgs a, int n_units, int wcols) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-  // layout: [NW waves][klist 128 B | woff LKCHUNK*4 B | aoff LKCHUNK*16*4 B] then the weights
-  constexpr int WAVE_BYTES = 128 + LKCHUNK * 4 + LKCHUNK * 16 * 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  unsigned char *kl = lds_raw + wave * WAVE_BYTES;
-  uint32_t *wo = reinterpret_cast<uint32_t *>(kl + 128);
-  uint32_t *ao = wo + LKCHUNK;
-  const unsigned char *wl = lds_raw + NW * WAVE_BYTES;
-  const uint32_t ub = (uint32_t)wcols * 16u;  // bytes of one unit in LDS
-  if (a.abort_flag && *a.abort_flag) return;
-  {
-    // stage: unit u, column n < wcols: 16 bytes from the padded unit-major array (256 B per unit)
-    const int nvec = n_units * wcols;
-    const float4 *src = reinterpret_cast<const float4 *>(a.Wu);
-    float4 *dst = reinterpret_cast<float4 *>(lds_raw + NW * WAVE_BYTES);
-    for (int i = threadIdx.x; i < nvec; i += NW * 64) {
-      const int u = wcols == 16 ? i >> 4 : i >> 3, n = i & (wcols - 1);
-      dst[i] = src[u * 16 + n];
-    }
-  }
-  const int count = *a.n_out;
-  const int ntiles = (count + 15) >> 4;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
-  const uint32_t ldn32 = (uint32_t)a.ldn;
-  const int upk = a.upk;
-  const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
-  const uint32_t wlane = (uint32_t)(r & (wcols - 1)) * 16u;  // lanes past the real columns re-read a real one (never stored)
-  const int kstep = 4 / upk, cstep = 4 % upk;
-  const int col = r;
-  const bool cv = col < a.cout;
-  const float esc = cv ? a.scale[col] : 0.f, esh = cv ? a.shift[col] : 0.f;
-  const float efw = (FIN && cv) ? a.fin_w[col] : 0.f;
-  const int tile_first = blockIdx.x * NW + wave;
-  uint32_t pw0 = 0u, pw1 = 0u;
-  if (tile_first < a.tile_cap) {
-    pw0 = a.tmask[(size_t)tile_first * 4 + (lane >> 5)];
-    pw1 = a.tmask[(size_t)tile_first * 4 + 2 + (lane >> 5)];
-  }
-  __syncthreads();  // weights are in LDS
-  for (int tile = tile_first; tile < ntiles; tile += gridDim.x * NW) {
-    const int row0 = tile * 16;
-    __builtin_amdgcn_wave_barrier();
-    uint32_t w0 = pw0, w1 = pw1;
-    if (tile != tile_first) {
-      const uint32_t *m = a.tmask + (size_t)tile * 4;
-      w0 = m[lane >> 5];
-      w1 = m[2 + (lane >> 5)];
-    }
-    const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = lane < 32 && ((w1 >> (lane & 31)) & 1u);
-    const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    const int n0 = __popcll(bal0);
-    if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)((lane >> 5) * 27 + (lane & 31));
-    if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(54 + lane);
-    const int nk = n0 + __popcll(bal1);
-    __builtin_amdgcn_wave_barrier();
-
-    floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < nk; kc += LKCHUNK) {
-      const int nkc = min(LKCHUNK, nk - kc);
-      __builtin_amdgcn_wave_barrier();
-      {
-        constexpr int NST = LKCHUNK * 16 / 64;
-        const int row = row0 + r;
-        const bool rv = row < count;
-        int vals[NST];
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-          const int kkl = q + 4 * i;
-          const bool act = rv && kkl < nkc;
-          const uint32_t off = act ? ((uint32_t)kl[kc + kkl] * ldn32 + (uint32_t)row) * 4u : OOR;
-          vals[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NST; ++i) {
-          const int kkl = q + 4 * i;
-          const bool act = rv && kkl < nkc;
-          if (kkl < nkc) ao[kkl * 16 + r] = (act && vals[i] >= 0) ? (uint32_t)vals[i] * ldi4 : OOR;
-        }
-      }
-      if (lane < nkc) wo[lane] = (uint32_t)kl[kc + lane] * (uint32_t)upk * ub;
-      __builtin_amdgcn_wave_barrier();
-      const int ju0 = kc * upk, ju1 = (kc + nkc) * upk;
-      int jl = ju0 + q;
-      int kk = (int)(((float)jl + 0.5f) * a.inv_upk);
-      int c4 = jl - kk * upk;
-      kk -= kc;
-      for (int jb = ju0; jb < ju1; jb += 4 * G) {
-        u32x4 va[G];
-        uint32_t ob[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const bool valid = jb + 4 * g + q < ju1;
-          const int kkc = min(kk, LKCHUNK - 1);
-          const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
-          ob[g] = valid ? wo[kkc] + (uint32_t)c4 * ub + wlane : wlane;  // past the list: zero A times a real (finite) weight
-          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
-          c4 += cstep;
-          kk += kstep;
-          const int wrap = c4 >= upk ? 1 : 0;
-          c4 -= wrap ? upk : 0;
-          kk += wrap;
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const u32x4 vb = *reinterpret_cast<const u32x4 *>(wl + ob[g]);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb.x), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb.y), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb.z), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb.w), acc, 0, 0, 0);
-        }
-      }
-    }
-    if (DS) {
-      const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in2, 0, (int)a.in2_bytes, 0x00020000);
-      const int row = row0 + r;
-      const uint32_t rowoff = row < count ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) : OOR;
-      const uint32_t wbase = (uint32_t)(a.K * upk) * ub + wlane;
-      for (int jb = 0; jb < a.upk2; jb += 4 * G) {
-        u32x4 va[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int j = jb + 4 * g + q;
-          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, j < a.upk2 ? rowoff + (uint32_t)j * 16u : OOR, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int j = min(jb + 4 * g + q, a.upk2 - 1);
-          const u32x4 vb = *reinterpret_cast<const u32x4 *>(wl + wbase + (uint32_t)j * ub);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb.x), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb.y), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb.z), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb.w), acc, 0, 0, 0);
-        }
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int ro = row0 + q * 4 + i;
-      float y = acc[i] * esc + esh;
-      if (a.res && cv && ro < count) y += a.res[(size_t)ro * a.ldr + col];
-      if (a.relu) y = fmaxf(y, 0.f);
-      if (cv && ro < count) a.out[(size_t)ro * a.ldo + col] = y;
-      if (FIN) {
-        float f = cv ? y * efw : 0.f;
-        f += __shfl_xor(f, 1, 64);
-        f += __shfl_xor(f, 2, 64);
-        f += __shfl_xor(f, 4, 64);
-        if (r == 0 && ro < count) a.fin_out[ro] = f + a.fin_b;
-      }
-    }
-  }
-}
-
 // Transposed (up-sampling) convolution, parent-stationary (App. A.10: every fine voxel v receives exactly one
 // term, in[parent(v)] @ W[oct(v)]).  Run output-stationary through k_conv it executes all 8 offsets for every
 // fine tile although one row in eight is live per offset; here a workgroup owns a tile of 16 PARENT rows:

@@ -92,16 +92,6 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_W4
 #define SPS_W4 4
 #endif
-#ifndef SPS_GL2
-#define SPS_GL2 4  // k_conv_lds, two workgroups of 14 waves per CU (<= 72 VGPRs): gather groups in flight per wave
-#endif
-#ifndef SPS_GL1
-#define SPS_GL1 8  // k_conv_lds, one workgroup of 16 waves per CU (<= 128 VGPRs)
-#endif
-#ifndef SPS_LDSW_DEFAULT
-#define SPS_LDSW_DEFAULT 0
-#endif
-
 #include "keys_hash.inc.h"
 #include "grid_kernels.inc.h"
 #include "map_kernels.inc.h"
@@ -605,45 +595,6 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   }
   const bool ds = cs.ds_cin > 0;
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
-  // NT = 1 layers over a kernel map: optionally the whole weight set of the layer in LDS (k_conv_lds).
-  // SPS_LDSW: bit l = use it at level l (DIAGNOSTICS / tuning; default from the measurements in DESIGN.md)
-  static const int lds_levels = [] { const char *e = getenv("SPS_LDSW"); return e ? atoi(e) : SPS_LDSW_DEFAULT; }();
-  if (((lds_levels >> cc.level_out) & 1) && a.NT == 1 && g.S == 1 && a.tmask && a.nbr) {
-    const int n_units = cs.K * cs.upk() + cs.ds_cin / 4;
-    const int wcols = cs.cout <= 8 ? 8 : 16;
-    constexpr int WAVE_BYTES = 128 + LKCHUNK * 4 + LKCHUNK * 16 * 4;
-    const size_t wbytes = (size_t)n_units * wcols * 16;
-    // two workgroups of 14 waves per CU when they fit (7 waves / SIMD like k_conv), else one of 16 waves
-    const bool two = 2 * ((size_t)14 * WAVE_BYTES + wbytes) <= 160 * 1024;
-    const int nw = two ? 14 : 16;
-    const size_t lds = (size_t)nw * WAVE_BYTES + wbytes;
-    if (lds <= 160 * 1024) {
-      int64_t tiles_cap = c->capl[cc.level_out] / 16;
-      int64_t gl = std::min<int64_t>((tiles_cap + nw - 1) / nw, (int64_t)256 * (two ? 2 : 1));
-      if (gl < 16) gl = 16;
-      const dim3 gridl((unsigned)gl);
-#define SPS_LDS_LAUNCH(NW_, G_, W_, DS_, FIN_)                                                                    \
-  do {                                                                                                            \
-    static const bool attr_ = [] {                                                                                \
-      return hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_lds<NW_, G_, W_, DS_, FIN_>),             \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;           \
-    }();                                                                                                          \
-    if (!attr_) return fail(SPS_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");                \
-    hipLaunchKernelGGL((k_conv_lds<NW_, G_, W_, DS_, FIN_>), gridl, dim3(NW_ * 64), lds, st, a, n_units, wcols);   \
-  } while (0)
-      if (two) {
-        if (cc.fin) SPS_LDS_LAUNCH(14, SPS_GL2, 7, true, true);
-        else if (ds) SPS_LDS_LAUNCH(14, SPS_GL2, 7, true, false);
-        else SPS_LDS_LAUNCH(14, SPS_GL2, 7, false, false);
-      } else {
-        if (cc.fin) SPS_LDS_LAUNCH(16, SPS_GL1, 4, true, true);
-        else if (ds) SPS_LDS_LAUNCH(16, SPS_GL1, 4, true, false);
-        else SPS_LDS_LAUNCH(16, SPS_GL1, 4, false, false);
-      }
-#undef SPS_LDS_LAUNCH
-      return SPS_OK;
-    }
-  }
   if (cc.fin) {
     hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
     return SPS_OK;
