@@ -1,6 +1,6 @@
-"""Per-wave timeline of one conv launch (DIAGNOSTIC): builds libsps_hip.so with -DSPS_WAVE_TRACE on the GPU box,
-records wall-clock stamps (100 MHz) at wave entry / first tile / exit for the layer named by --layer, prints the
-distribution of start times and lifetimes, then restores the product library.
+"""Per-wave timeline of one conv launch (DIAGNOSTIC): builds a PRIVATE copy of the library with -DSPS_WAVE_TRACE on the
+GPU box (the bindings load $SPS_LIB; the product libsps_hip.so is never touched), records wall-clock stamps (100 MHz) at
+wave entry / first tile / exit for the layer named by --layer, prints the distribution of start times and lifetimes.
   gpurun -- python tools/wave_trace.py --layer block8.0.conv1"""
 import argparse, ctypes as C, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,8 +9,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--layer", default="block8.0.conv1")
 ap.add_argument("--flags", default="")
 args = ap.parse_args()
-lib = os.path.join(ROOT, "sps_amd/csrc/libsps_hip.so")
-shutil.copy(lib, "/tmp/libsps_hip.orig.so")
+import tempfile
+lib = os.path.join(tempfile.mkdtemp(prefix="sps_trace_"), "libsps_hip_trace.so")
+os.environ["SPS_LIB"] = lib
 try:
     subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSPS_WAVE_TRACE",
                            *args.flags.split(), "-o", lib, os.path.join(ROOT, "sps_amd/csrc/sps_hip.hip")],
@@ -53,4 +54,4 @@ try:
     conc = [int(((start[w] <= e) & (end[w] > e)).sum()) for e in edges]
     print("resident working waves at", " ".join(f"{e:.0f}" for e in edges), "us:\n  ", conc)
 finally:
-    shutil.copy("/tmp/libsps_hip.orig.so", lib)
+    shutil.rmtree(os.path.dirname(lib), ignore_errors=True)
