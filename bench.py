@@ -109,13 +109,17 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def build_workload(config, rank, azimuth, seq_scans, vs):
+def build_workload(config, rank, azimuth, seq_scans, vs, scenes=4):
     """Returns (list of [N,6] float32 numpy batches that the steps cycle through, n_batches per step, description)."""
     from sps_amd import synthetic
     if config == 2:
-        sc = synthetic.make_scene(scan_seed=1 + rank, n_azimuth=azimuth, voxel_size=vs)
-        return [sc["batch"]], 1, ("BASELINE config 2: single ~100k-pt LiDAR-like scan + variant-B submap, 0.1 m voxel, "
-                                  "CustomMinkUNet14 fp32, 1 scan per step per GPU")
+        # `scenes` distinct scans (different noise / labels against the same map), cycled: no step re-reads the previous
+        # step's input out of the caches
+        map_points = synthetic.build_map(n_azimuth=azimuth)
+        scans = [synthetic.make_scene(scan_seed=1 + rank + 100 * i, n_azimuth=azimuth, voxel_size=vs, map_points=map_points)["batch"]
+                 for i in range(max(1, scenes))]
+        return scans, 1, (f"BASELINE config 2: single ~100k-pt LiDAR-like scan + variant-B submap, 0.1 m voxel, "
+                          f"CustomMinkUNet14 fp32, 1 scan per step per GPU ({len(scans)} distinct scans cycled)")
     if config == 3:
         n = max(4, (seq_scans // 4) * 4)
         scans = list(synthetic.make_sequence(n, first_seed=100 + 1000 * rank, voxel_size=vs, n_azimuth=azimuth))
@@ -137,6 +141,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, help="BASELINE config: 2 (default, the headline), 3 (batch = 4 sequence), 4 (NCLT-like)")
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
     ap.add_argument("--seq-scans", type=int, default=32, help="config 3: distinct scans of the sequence (cycled)")
+    ap.add_argument("--scenes", type=int, default=4, help="config 2: distinct scans cycled through the steps")
     ap.add_argument("--streams", type=int, default=23,
                     help="independent steps in flight per GPU (one HIP stream + native context each); 1 = strictly serial. "
                          "Clamped to --steps.  The HIP runtime multiplexes streams onto 4 hardware queues: counts of the "
@@ -183,7 +188,7 @@ def main():
     vs = CFG["MODEL"]["VOXEL_SIZE"]
 
     # ---- workload (host generation is not timed) ----------------------------------------------------------------
-    batches_np, nb, workload = build_workload(args.config, rank, args.azimuth, args.seq_scans, vs)
+    batches_np, nb, workload = build_workload(args.config, rank, args.azimuth, args.seq_scans, vs, args.scenes)
     if args.order == "morton":
         batches_np = [morton_sorted(b, vs) for b in batches_np]
         workload += " [rows pre-sorted in Morton order: diagnostic]"

@@ -228,8 +228,8 @@ int sps_radius_fill(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64_
  * sps_train_forward: params_dev is the flat parameter blob ON THE DEVICE in the layout of sps_weights_tensor_info
  *   (kernels [K][C_in][C_out], BN weight / bias / running_mean / running_var, final.bias); the running statistics are
  *   ignored: BatchNorm normalises with the batch statistics of the active rows (train mode, eps = 1e-5) and
- *   batch_stats_dev (optional, [2 * sum of BN widths] floats: per conv in layer order the batch mean then the BIASED
- *   batch variance of its BN) lets the caller update running_mean / running_var as nn.BatchNorm1d does.  scores_dev [n]
+ *   batch_stats_dev (optional, [3 * sum of BN widths] floats: per conv in layer order the batch mean, the BIASED
+ *   and the UNBIASED batch variance of its BN) lets the caller update running_mean / running_var as nn.BatchNorm1d does.  scores_dev [n]
  *   = sigmoid(final(...)) sliced to the points, as sps_forward.  The activations the backward needs stay in ctx.
  * sps_train_backward: dscores_dev [n] = d(loss)/d(scores); scores_dev the forward's output; grad_dev receives
  *   d(loss)/d(parameter) in the blob layout (zeros in the running-statistics slots).  Deterministic (fixed-order

@@ -496,6 +496,32 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   return g;
 }
 
+// k_conv instantiation for a launch geometry (column tiles per wave x splits) -- shared by inference and training
+int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t st) {
+#define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
+  do {                                                                                            \
+    if (ds)                                                                                       \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(256), 0, st, a);     \
+    else                                                                                          \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(256), 0, st, a);    \
+  } while (0)
+  const int key = g.ntw * 10 + g.S;
+  switch (key) {
+    case 11: SPS_LAUNCH(1, SPS_G1, SPS_W1, 1); break;
+    case 12: SPS_LAUNCH(1, SPS_G1, SPS_WS, 2); break;
+    case 14: SPS_LAUNCH(1, SPS_G1, SPS_WS, 4); break;
+    case 21: SPS_LAUNCH(2, SPS_G2, SPS_W2, 1); break;
+    case 22: SPS_LAUNCH(2, SPS_G2, SPS_W2, 2); break;
+    case 24: SPS_LAUNCH(2, SPS_G2, SPS_W2, 4); break;
+    case 41: SPS_LAUNCH(4, SPS_G4, SPS_W4, 1); break;
+    case 42: SPS_LAUNCH(4, SPS_G4, SPS_W4, 2); break;
+    case 44: SPS_LAUNCH(4, SPS_G4, SPS_W4, 4); break;
+    default: return fail(SPS_ERR_INVALID, "unsupported conv geometry ntw = %d, S = %d", g.ntw, g.S);
+  }
+#undef SPS_LAUNCH
+  return SPS_OK;
+}
+
 int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   const NetSpec &s = *c->net;
   const int ci = s.find_conv(cc.name);
@@ -599,28 +625,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
     return SPS_OK;
   }
-#define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
-  do {                                                                                            \
-    if (ds)                                                                                       \
-      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(256), 0, st, a);     \
-    else                                                                                          \
-      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(256), 0, st, a);    \
-  } while (0)
-  const int key = g.ntw * 10 + g.S;
-  switch (key) {
-    case 11: SPS_LAUNCH(1, SPS_G1, SPS_W1, 1); break;
-    case 12: SPS_LAUNCH(1, SPS_G1, SPS_WS, 2); break;
-    case 14: SPS_LAUNCH(1, SPS_G1, SPS_WS, 4); break;
-    case 21: SPS_LAUNCH(2, SPS_G2, SPS_W2, 1); break;
-    case 22: SPS_LAUNCH(2, SPS_G2, SPS_W2, 2); break;
-    case 24: SPS_LAUNCH(2, SPS_G2, SPS_W2, 4); break;
-    case 41: SPS_LAUNCH(4, SPS_G4, SPS_W4, 1); break;
-    case 42: SPS_LAUNCH(4, SPS_G4, SPS_W4, 2); break;
-    case 44: SPS_LAUNCH(4, SPS_G4, SPS_W4, 4); break;
-    default: return fail(SPS_ERR_INVALID, "unsupported conv geometry ntw = %d, S = %d", g.ntw, g.S);
-  }
-#undef SPS_LAUNCH
-  return SPS_OK;
+  return launch_k_conv(a, g, ds, grid, st);
 }
 
 // Host-side permutation of one kernel [K][cin][cout] into the unit-major MFMA B-fragment order

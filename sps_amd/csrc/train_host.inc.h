@@ -148,7 +148,7 @@ int train_reserve(sps_ctx *c) {
   TALLOC(t->bn_part, double, (size_t)s.bns.size() * BN_WG * 2 * BN_MAXC);
   TALLOC(t->bn_bpart, double, (size_t)BN_WG * 2 * BN_MAXC);
   TALLOC(t->fin_part, double, (size_t)BN_WG * 9);
-  TALLOC(t->batch_stats, float, s.ss_numel);
+  TALLOC(t->batch_stats, float, s.ss_numel / 2 * 3);
   TALLOC(t->ones, float, 128);
   TALLOC(t->zeros, float, 128);
   TALLOC(t->c0part, float, (size_t)256 * 1000);
@@ -156,7 +156,7 @@ int train_reserve(sps_ctx *c) {
   std::vector<float> one(128, 1.f);
   HIP_TRY(hipMemcpy(t->ones, one.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
   HIP_TRY(hipMemset(t->zeros, 0, 128 * sizeof(float)));
-  HIP_TRY(hipMemset(t->batch_stats, 0, s.ss_numel * sizeof(float)));
+  HIP_TRY(hipMemset(t->batch_stats, 0, s.ss_numel / 2 * 3 * sizeof(float)));
   t->cap = cap;
   return SPS_OK;
 }
@@ -283,9 +283,13 @@ int conv_plain(sps_ctx *c, hipStream_t st, TKind gather, int level_rows, int K, 
   }  // T_LIN: identity (nbr = tmask = null)
   int64_t gx = (c->cap / 64) >> level_rows;
   gx = std::min<int64_t>(std::max<int64_t>(gx, 64), 4096);
-  const dim3 grid((unsigned)a.NT, (unsigned)gx, 1u);  // one column tile per wave (any NT), no split
-  hipLaunchKernelGGL((k_conv<1, SPS_G1, SPS_W1, false, false, 1>), grid, dim3(256), 0, st, a);
-  return SPS_OK;
+  // the inference geometry of the level (column tiles per wave x splits); NT = 3 / 6 (gradients wrt 48 / 96 channels)
+  // only divide by one column tile per wave
+  Geometry g = conv_geometry(level_rows, K, cin, a.NT);
+  if (a.NT % g.ntw != 0) g.ntw = 1;
+  a.S = g.S;
+  const dim3 grid((unsigned)(a.NT / g.ntw), (unsigned)(gx * g.S), 1u);
+  return launch_k_conv(a, g, false, grid, st);
 }
 
 int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, int cin, int cout, const float *x, int ldx,
@@ -314,7 +318,11 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
     w.tmask = L.tmdown;
   }
   // rows are cut into chunks (partial sums added in chunk order): enough waves for the fine levels, few for the coarse
-  int nchunk = level_rows <= 1 ? 16 : level_rows == 2 ? 8 : 4;
+  // enough waves to fill the chip (~16 k) whatever the layer's K x tile count; every wave walks its chunk's tiles as a
+  // chain of dependent loads, so short chunks also bound the launch's duration
+  int nchunk = (int)std::min<int64_t>(128, std::max<int64_t>(4, 16384 / ((int64_t)K * w.MT * w.NT)));
+  const int64_t tiles_cap = (c->capl[level_rows] / 16);
+  while (nchunk > 4 && (int64_t)nchunk * 8 > tiles_cap) nchunk >>= 1;   // at least ~8 tiles per chunk
   while ((size_t)K * w.MT * w.NT * nchunk * 256 > t->slab_floats && nchunk > 1) nchunk >>= 1;
   if ((size_t)K * w.MT * w.NT * nchunk * 256 > t->slab_floats) return fail(SPS_ERR_INVALID, "wgrad slab too small");
   w.nchunk = nchunk;
@@ -396,14 +404,14 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
     const float *gamma = t->blob + bn.off, *beta = gamma + bn.c;
     hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * cs.cout, 256, 1024)), dim3(256), 0, st, z, cs.cout,
                        c->counts + lo, cs.cout, part, gamma, beta, op.res.p, op.res.ld, op.relu, op.out.p, op.out.ld,
-                       t->batch_stats + cs.ss_off);
+                       t->batch_stats + cs.ss_off / 2 * 3);
   }
   // final 1x1 conv + bias, slice, sigmoid (models.py:28-29)
   const ConvSpec &fs = s.convs[s.find_conv("final")];
   hipLaunchKernelGGL(k_slice_head, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->b8o, 8, c->lv[0].inv, (int)n,
                      t->blob + fs.w_off, t->blob + s.bias_off, 1, 1, scores, (int64_t)1, (const int *)nullptr);
   if (batch_stats_dev)
-    HIP_TRY(hipMemcpyAsync(batch_stats_dev, t->batch_stats, (size_t)s.ss_numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(batch_stats_dev, t->batch_stats, (size_t)s.ss_numel / 2 * 3 * sizeof(float), hipMemcpyDeviceToDevice, st));
   // the block hashes go back to "free" (the inference forward does this in its tail kernel)
   {
     const PyramidArgs pa = pyramid_args(c);

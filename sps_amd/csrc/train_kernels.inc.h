@@ -38,10 +38,18 @@ __global__ void k_permute_weights(const float *__restrict__ W, int K, int cin, i
 // ------------------------------------------------------------------------------------------
 // train-mode BatchNorm (ME.MinkowskiBatchNorm = nn.BatchNorm1d over the V active rows; resnet.py:93-94, eps = 1e-5)
 // ------------------------------------------------------------------------------------------
-constexpr int BN_WG = 64;      // partial-sum workgroups per reduction (fixed: the combine order is part of the result)
+constexpr int BN_WG = 256;     // partial-sum workgroups per reduction (fixed: the combine order is part of the result)
 constexpr int BN_MAXC = 96;
 
-// pass 1: per workgroup, per channel: sum z and sum z^2 over its contiguous slice of rows (f64)
+// pass 1: per workgroup, per channel: sum z and sum z^2 over its contiguous slice of rows (f64).
+// C is 8, 16, 32 or 64: a wave covers 64 / C rows x C channels per step (lane = rsub * C + c); the row sub-sums meet in
+// a fixed shuffle tree, the four waves in LDS in wave order -- the result does not depend on timing.
+__device__ inline void bn_wave_reduce(double &s0, double &s1, int C) {
+  for (int o = 32; o >= C; o >>= 1) {
+    s0 += __shfl_down(s0, o, 64);
+    s1 += __shfl_down(s1, o, 64);
+  }
+}
 __global__ __launch_bounds__(256) void k_bn_stats(const float *__restrict__ Z, int ld, const int *__restrict__ n_rows, int C,
                                                    double *__restrict__ part /* [BN_WG][2][C] */) {
   __shared__ double red[2][4][BN_MAXC];
@@ -49,38 +57,29 @@ __global__ __launch_bounds__(256) void k_bn_stats(const float *__restrict__ Z, i
   const int per = (n + BN_WG - 1) / BN_WG;
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // a wave walks rows r0 + wave, +4, ...; lane c (and c + 64) owns channel c
-  double s0[2] = {0, 0}, s1[2] = {0, 0};
-  for (int r = r0 + wave; r < r1; r += 4) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = lane + 64 * h;
-      if (c < C) {
-        const double v = (double)Z[(size_t)r * ld + c];
-        s0[h] += v;
-        s1[h] += v * v;
-      }
-    }
+  const int rpw = 64 / C, c = lane % C, rsub = lane / C;   // rows per wave step
+  double s0 = 0, s1 = 0;
+  for (int r = r0 + wave * rpw + rsub; r < r1; r += 4 * rpw) {
+    const double v = (double)Z[(size_t)r * ld + c];
+    s0 += v;
+    s1 += v * v;
   }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = lane + 64 * h;
-    if (c < C) {
-      red[0][wave][c] = s0[h];
-      red[1][wave][c] = s1[h];
-    }
+  bn_wave_reduce(s0, s1, C);
+  if (lane < C) {
+    red[0][wave][c] = s0;
+    red[1][wave][c] = s1;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    const int w = i / C, c = i - w * C;
-    part[((size_t)blockIdx.x * 2 + w) * C + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+    const int w = i / C, cc = i - w * C;
+    part[((size_t)blockIdx.x * 2 + w) * C + cc] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
   }
 }
 
 // combine the BN_WG partials in index order -> mean / invstd of channel c (every workgroup of the consumer recomputes
 // them: BN_WG * C adds, cheaper than a launch).  Also the batch statistics the host folds into running_mean / _var.
 __device__ inline void bn_finish(const double *__restrict__ part, int C, int n, int c, float &mean, float &invstd,
-                                 float *__restrict__ batch_stats /* [2][C]: mean, biased var; or null */) {
+                                 float *__restrict__ batch_stats /* [3][C]: mean, biased var, unbiased var; or null */) {
   double s0 = 0, s1 = 0;
   for (int w = 0; w < BN_WG; ++w) {
     s0 += part[((size_t)w * 2 + 0) * C + c];
@@ -94,6 +93,7 @@ __device__ inline void bn_finish(const double *__restrict__ part, int C, int n, 
   if (batch_stats) {
     batch_stats[c] = (float)m;
     batch_stats[C + c] = (float)var;
+    batch_stats[2 * C + c] = (float)(n > 1 ? var * ((double)n / (double)(n - 1)) : var);  // what running_var accumulates
   }
 }
 
@@ -134,32 +134,24 @@ __global__ __launch_bounds__(256) void k_bn_bwd_stats(const float *__restrict__ 
   const int per = (n + BN_WG - 1) / BN_WG;
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  double s0[2] = {0, 0}, s1[2] = {0, 0};
-  for (int r = r0 + wave; r < r1; r += 4) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int c = lane + 64 * h;
-      if (c < C) {
-        float g = dY[(size_t)r * ldg + c];
-        if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
-        const float xh = (Z[(size_t)r * ldz + c] - mean_s[c]) * inv_s[c];
-        s0[h] += (double)g;
-        s1[h] += (double)g * (double)xh;
-      }
-    }
+  const int rpw = 64 / C, c = lane % C, rsub = lane / C;
+  double s0 = 0, s1 = 0;
+  for (int r = r0 + wave * rpw + rsub; r < r1; r += 4 * rpw) {
+    float g = dY[(size_t)r * ldg + c];
+    if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
+    const float xh = (Z[(size_t)r * ldz + c] - mean_s[c]) * inv_s[c];
+    s0 += (double)g;
+    s1 += (double)g * (double)xh;
   }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const int c = lane + 64 * h;
-    if (c < C) {
-      red[0][wave][c] = s0[h];
-      red[1][wave][c] = s1[h];
-    }
+  bn_wave_reduce(s0, s1, C);
+  if (lane < C) {
+    red[0][wave][c] = s0;
+    red[1][wave][c] = s1;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    const int w = i / C, c = i - w * C;
-    bpart[((size_t)blockIdx.x * 2 + w) * C + c] = red[w][0][c] + red[w][1][c] + red[w][2][c] + red[w][3][c];
+    const int w = i / C, cc = i - w * C;
+    bpart[((size_t)blockIdx.x * 2 + w) * C + cc] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
   }
 }
 

@@ -131,10 +131,10 @@ class _TrainForward(torch.autograd.Function):
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             ctx = get_context(dev.index or 0, stream)
-            blob = torch.cat([sd[name].detach().reshape(-1).to(torch.float32) for name, _, _ in layout])
+            blob = module._flat_state(dev)          # parameters + BN buffers: views of one tensor in the native layout
             n = coordinates.shape[0]
             scores = torch.empty(n, dtype=torch.float32, device=dev)
-            n_stats = 2 * sum(int(sd[name].shape[-1]) for name, _, _ in layout if name.endswith(".kernel"))
+            n_stats = 3 * sum(int(sd[name].shape[-1]) for name, _, _ in layout if name.endswith(".kernel"))
             stats = torch.zeros(n_stats, dtype=torch.float32, device=dev)
             ctx.train_forward(blob.data_ptr(), blob.numel(), coordinates.data_ptr(), coordinates.stride(0), n,
                               module.voxel_size, scores.data_ptr(), stats.data_ptr(), stream)
@@ -198,14 +198,29 @@ class SPSModel(NativeBackboneModule):
         return scores
 
     @torch.no_grad()
-    def _update_running_stats(self, device, stats: torch.Tensor) -> None:
-        """nn.BatchNorm1d bookkeeping in train mode: running = (1 - m) running + m batch (m = 0.1, unbiased variance),
-        num_batches_tracked += 1.  The per-level row counts come from the context (one synchronisation per step)."""
-        ctx = get_context(device.index or 0, torch.cuda.current_stream(device).cuda_stream)
-        counts = ctx.level_counts()
-        level_of = {"bn0": 0, "bn1": 1, "bn2": 2, "bn3": 3, "bn4": 4, "bntr4": 3, "bntr5": 2, "bntr6": 1, "bntr7": 0,
-                    "block1": 1, "block2": 2, "block3": 3, "block4": 4, "block5": 3, "block6": 2, "block7": 1, "block8": 0}
+    def _flat_state(self, device) -> torch.Tensor:
+        """Every parameter and BatchNorm buffer of the backbone as a VIEW of one flat float32 device tensor in the native
+        blob layout (sps_weights_tensor_info): the training step hands the library one pointer instead of concatenating
+        194 tensors, and the optimiser's in-place updates keep it current.  Rebuilt when the storage moved (.cuda(), .to())."""
+        layout = _native.weight_layout(self.MinkUNet.out_channels)
         sd = self.MinkUNet.state_dict(keep_vars=True)
+        flat = getattr(self, "_flat", None)
+        ok = flat is not None and flat.device == device and all(
+            sd[name].data_ptr() == flat.data_ptr() + 4 * off and sd[name].dtype == torch.float32 for name, off, _ in layout)
+        if not ok:
+            flat = torch.cat([sd[name].detach().reshape(-1).to(device=device, dtype=torch.float32) for name, _, _ in layout])
+            for name, off, num in layout:
+                t = sd[name]
+                t.data = flat[off: off + num].view(t.shape)
+            self._flat = flat
+        return flat
+
+    @torch.no_grad()
+    def _update_running_stats(self, device, stats: torch.Tensor) -> None:
+        """nn.BatchNorm1d bookkeeping in train mode: running = (1 - m) running + m batch (m = 0.1; the library delivers
+        the batch mean and the UNBIASED batch variance), num_batches_tracked += 1 -- three multi-tensor kernels, no sync."""
+        sd = self.MinkUNet.state_dict(keep_vars=True)
+        rm, rv, nbt, bm, bv = [], [], [], [], []
         off = 0
         for name, _, _ in _native.weight_layout(self.MinkUNet.out_channels):
             if not name.endswith(".kernel"):
@@ -214,13 +229,18 @@ class SPSModel(NativeBackboneModule):
             c = int(sd[name].shape[-1])
             if conv != "final":
                 bn = _bn_of_conv(conv)
-                n = counts[level_of[bn.split(".")[0]]]
-                mean, var = stats[off: off + c], stats[off + c: off + 2 * c]
-                m = 0.1
-                sd[bn + ".bn.running_mean"].mul_(1 - m).add_(mean, alpha=m)
-                sd[bn + ".bn.running_var"].mul_(1 - m).add_(var * (n / max(n - 1, 1)), alpha=m)
-                sd[bn + ".bn.num_batches_tracked"].add_(1)
-            off += 2 * c
+                rm.append(sd[bn + ".bn.running_mean"])
+                rv.append(sd[bn + ".bn.running_var"])
+                nbt.append(sd[bn + ".bn.num_batches_tracked"])
+                bm.append(stats[off: off + c])
+                bv.append(stats[off + 2 * c: off + 3 * c])
+            off += 3 * c
+        m = 0.1
+        torch._foreach_mul_(rm, 1 - m)
+        torch._foreach_add_(rm, bm, alpha=m)
+        torch._foreach_mul_(rv, 1 - m)
+        torch._foreach_add_(rv, bv, alpha=m)
+        torch._foreach_add_(nbt, 1)
 
 
 class SPSNet(nn.Module):
