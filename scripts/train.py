@@ -7,6 +7,9 @@ model, optimiser and scheduler, scripts/train.py:30-66) with the Lightning ``Tra
 ``last.ckpt`` every epoch and the best-``val_loss`` one (ModelCheckpoint(monitor="val_loss", save_last=True),
 train.py:37-42).
 
+Under ``python -m torch.distributed.run --nproc-per-node W`` the batches are sharded i mod W over the GPUs and the ranks
+average ONE flat gradient tensor per step (a single RCCL all-reduce of 7.4 MB); the reference trains on one GPU.
+
 ``--synthetic N`` trains on N synthetic scans (no $DATA tree exists in this environment): labels are a smooth function
 of position so that there is something to learn.
 """
@@ -49,8 +52,21 @@ def synthetic_loaders(n, voxel_size):
 @click.option("--out", type=str, default=LOG_DIR, help="directory for checkpoints")
 def main(config, n_synth, max_epochs, out):
     cfg = yaml.safe_load(open(config))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("SPS_DIST_BACKEND", "nccl")          # gloo only to exercise the control flow on one GPU
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        # data-parallel over the GPUs of one node: batch i -> rank i mod W, identical initial weights (same seed), the
+        # flat gradient averaged by ONE all-reduce per step (RCCL over xGMI; sps_amd/models/models.py::_TrainForward)
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    torch.manual_seed(0)
 
     # Load data and model (train.py:33-35)
     if n_synth:
@@ -66,6 +82,8 @@ def main(config, n_synth, max_epochs, out):
     os.makedirs(ckpt_dir, exist_ok=True)
 
     def save(path, epoch, val_loss):
+        if rank != 0:
+            return
         torch.save({"epoch": epoch, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                     "hyper_parameters": cfg, "val_loss": val_loss}, path)
 
@@ -73,7 +91,12 @@ def main(config, n_synth, max_epochs, out):
     for epoch in range(epochs):
         model.train()
         t0, losses = time.time(), []
+        n_even = len(train_loader) // world * world     # every rank takes the same number of steps (one all-reduce each)
         for i, batch in enumerate(train_loader):
+            if i >= n_even:
+                break
+            if i % world != rank:
+                continue
             optimizer.zero_grad(set_to_none=True)
             out_ = model.training_step(batch.to(dev, non_blocking=True), i)
             out_["loss"].backward()
@@ -90,13 +113,25 @@ def main(config, n_synth, max_epochs, out):
         val_loss = float(torch.stack(vl).mean()) if vl else float("nan")
         val_r2 = float(torch.stack(vr).mean()) if vr else float("nan")
         scheduler.step()
-        print(f"epoch {epoch:03d}  train_loss {train_loss:.5f}  val_loss {val_loss:.5f}  val_r2 {val_r2:.4f}  "
-              f"lr {optimizer.param_groups[0]['lr']:.2e}  {len(losses) / max(time.time() - t0, 1e-9):.1f} steps/s")
+        if world > 1:                                   # every rank validated the whole split with the same weights
+            import torch.distributed as dist
+            t = torch.tensor([train_loss, float(len(losses))], dtype=torch.float64, device=dev)
+            t[0] *= t[1]
+            dist.all_reduce(t)
+            train_loss = float(t[0] / max(float(t[1]), 1.0))
+        if rank == 0:
+            print(f"epoch {epoch:03d}  train_loss {train_loss:.5f}  val_loss {val_loss:.5f}  val_r2 {val_r2:.4f}  "
+                  f"lr {optimizer.param_groups[0]['lr']:.2e}  {len(losses) * world / max(time.time() - t0, 1e-9):.1f} steps/s")
         save(os.path.join(ckpt_dir, "last.ckpt"), epoch, val_loss)
         if val_loss < best:
             best = val_loss
             save(os.path.join(ckpt_dir, f"{cfg['EXPERIMENT']['ID']}_epoch={epoch:03d}_val_loss={val_loss:.4f}.ckpt"), epoch, val_loss)
-    print("best val_loss", best, "checkpoints in", ckpt_dir)
+    if rank == 0:
+        print("best val_loss", best, "checkpoints in", ckpt_dir)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

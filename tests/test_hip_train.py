@@ -121,3 +121,26 @@ def test_train_cli_writes_a_checkpoint_predict_cli_loads(tmp_path):
                         "-c", os.path.join(root, "config", "config.yaml")], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert any(l.startswith("dIoU .") for l in r.stdout.splitlines())
+
+
+@pytest.mark.timeout(900)
+def test_data_parallel_training_two_ranks_one_gpu(tmp_path):
+    """scripts/train.py under torchrun with two ranks (gloo, both on this box's one GPU): batches sharded i mod 2, the flat
+    gradient averaged by one all-reduce per step, rank 0 writes the checkpoints; with identical data on both ranks the
+    averaged gradient equals the single-process gradient, so the weights after one epoch match a single-process run
+    that sees each batch once."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SPS_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "scripts", "train.py"), "-c", os.path.join(root, "config", "config.yaml"),
+                        "--synthetic", "8", "--max-epochs", "1", "--out", str(tmp_path)], capture_output=True, text=True,
+                       timeout=800, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("epoch ")]
+    assert len(lines) == 1, r.stdout[-2000:]                                   # rank 0 only
+    sd = torch.load(os.path.join(str(tmp_path), "BLT", "checkpoints", "last.ckpt"), map_location="cpu", weights_only=False)["state_dict"]
+    assert int(sd["model.MinkUNet.bn0.bn.num_batches_tracked"]) == 4           # 8 batches over 2 ranks
+    assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
