@@ -25,7 +25,8 @@ def per_scan(d, counter):
     a, b = starts[-2], starts[-1]                    # one steady-state scan
     tot = collections.defaultdict(float)
     for r in rows[a:b]:
-        tot[r["Kernel_Name"].split("(")[0].split("::")[-1][:40]] += float(r["Counter_Value"])
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        tot[name.split("(")[0][:48]] += float(r["Counter_Value"])
     return tot
 
 fetch = per_scan(sys.argv[1], "FETCH_SIZE")
