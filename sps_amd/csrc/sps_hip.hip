@@ -183,6 +183,7 @@ struct sps_ctx {
   int64_t hash_slots = 0;  // sum of hcapl
   float lfrac[SPS_NUM_LEVELS] = {1.f, 1.f, 1.f, 1.f, 1.f};
   bool compact = false, regrow = false;
+  uint64_t arena_gen = 0;  // bumped by every (re)allocation of the arena: dependants (training views) re-derive their pointers
   int64_t last_n = 0;    // points of the last forward
   bool have_weights = false;
   std::vector<void *> allocs;
@@ -390,6 +391,7 @@ int reserve(sps_ctx *c, int64_t n) {
   c->cap = cap;
   c->hcap = hcap;
   c->last_n = 0;
+  ++c->arena_gen;
   HIP_TRY(hipMemset(c->zero_region, 0, zr_words * sizeof(uint32_t)));  // counters + every mask word once
   // the block hashes start clean here (allocation time), not in the first forward: every later forward cleans up
   // after itself, so a context that was reserved up front issues no fill in its steady state

@@ -34,6 +34,7 @@ struct TOp {
 
 struct sps_train {
   int64_t cap = 0;
+  uint64_t arena_gen = 0;  // generation of the context's arena the views below point into
   const NetSpec *net = nullptr;
   std::vector<void *> allocs;
   float *blob = nullptr, *grad = nullptr;  // parameters / gradients, flat [numel]
@@ -89,7 +90,7 @@ std::vector<FeatDesc> feat_list(sps_ctx *c) {
 int train_reserve(sps_ctx *c) {
   if (!c->train) c->train = new sps_train();
   sps_train *t = c->train;
-  if (t->cap == c->cap && t->net == c->net && t->cap > 0) return SPS_OK;
+  if (t->cap == c->cap && t->net == c->net && t->cap > 0 && t->arena_gen == c->arena_gen) return SPS_OK;
   HIP_TRY(hipDeviceSynchronize());
   train_free(t);
   const NetSpec &s = *c->net;
@@ -158,6 +159,7 @@ int train_reserve(sps_ctx *c) {
   HIP_TRY(hipMemset(t->zeros, 0, 128 * sizeof(float)));
   HIP_TRY(hipMemset(t->batch_stats, 0, s.ss_numel / 2 * 3 * sizeof(float)));
   t->cap = cap;
+  t->arena_gen = c->arena_gen;
   return SPS_OK;
 }
 

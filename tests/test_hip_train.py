@@ -34,7 +34,7 @@ def test_training_step_gradients_match_autograd_oracle():
     params = O.random_params(seed=0)
     loss_ref, scores_ref, grads_ref, stats_ref = T.train_step(params, batch, VS)
     net, out, grads = native_step(params, batch)
-    assert float(out["loss"]) == pytest.approx(loss_ref, rel=2e-5)
+    assert float(out["loss"].detach()) == pytest.approx(loss_ref, rel=2e-5)
     net.train()
     with torch.enable_grad():
         s = net(torch.from_numpy(batch).cuda()).detach().cpu().numpy()
@@ -144,3 +144,28 @@ def test_data_parallel_training_two_ranks_one_gpu(tmp_path):
     sd = torch.load(os.path.join(str(tmp_path), "BLT", "checkpoints", "last.ckpt"), map_location="cpu", weights_only=False)["state_dict"]
     assert int(sd["model.MinkUNet.bn0.bn.num_batches_tracked"]) == 4           # 8 batches over 2 ranks
     assert all(torch.isfinite(v).all() for v in sd.values() if v.dtype.is_floating_point)
+
+
+def test_training_after_the_context_was_compact():
+    """A context that an engine switched to LiDAR-sized arenas goes back to full-size ones for training (the backward
+    indexes every level on the host's assumption that nothing was aborted), and the training arena follows the
+    re-allocation: gradients equal those of a fresh context."""
+    from sps_amd.models.models import get_context
+    batch = synthetic.small_scene(seed=3, n_scan=900)
+    params = O.random_params(seed=0)
+    _, out0, g0 = native_step(params, batch)                 # training arena exists now, sized for this cloud
+    c = get_context(0)
+    c.set_level_fractions(c.LIDAR_FRACTIONS)
+    net = net_from_params(params).cuda().eval().freeze()
+    s = net(torch.from_numpy(batch).cuda())                  # inference on the compact arena (this cloud overflows it: fine)
+    torch.cuda.synchronize()
+    try:
+        c.check_errors(torch.cuda.current_stream().cuda_stream)
+    except Exception:
+        pass
+    c.set_level_fractions(c.LIDAR_FRACTIONS)                 # compact again, same capacity: arena re-allocated
+    _, out1, g1 = native_step(params, batch)
+    assert float(out1["loss"].detach()) == float(out0["loss"].detach())
+    for k in g0:
+        np.testing.assert_array_equal(g0[k], g1[k], err_msg=k)
+    c.set_level_fractions(None)
