@@ -24,7 +24,7 @@
 //                 present-offset mask per 16-row tile
 //   features    : row-major f32 [V, C]; concatenations are strided views of one buffer (ME.cat costs nothing)
 // Diagnostic environment hooks (never needed in product use): SPS_GEOM_L<l>, SPS_CONV_MAX_WG,
-// SPS_DIAG_SKIP, SPS_NO_MERGE, SPS_GRID_SCALE; compile-time SPS_ABLATE_* (tools/ablate*.sh).
+// SPS_DIAG_SKIP, SPS_NO_MERGE, SPS_GRID_SCALE; compile-time SPS_ABLATE_* (private builds: tools/variant_sweep.sh).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -971,7 +971,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     int rc = reserve(c, n);
     if (rc != SPS_OK) return rc;
   }
-  // DIAGNOSTICS ONLY (tools/stage_cost.sh): SPS_DIAG_SKIP bit 0 = reuse the coordinate structures of the
+  // DIAGNOSTICS ONLY: SPS_DIAG_SKIP bit 0 = reuse the coordinate structures of the
   // previous forward (valid for an identical input), bit 1 = skip the convolutions.  Never set in product use.
   static const int diag_skip = [] { const char *e = getenv("SPS_DIAG_SKIP"); return e ? atoi(e) : 0; }();
   // DIAGNOSTICS: SPS_NO_MERGE bit i launches the parts of merged kernel i separately (0 rows|ancestors,
