@@ -288,6 +288,24 @@ def test_compact_arena_overflow_aborts_reports_and_recovers(net, params):
         assert c.arena_bytes() >= dense_bytes
         np.testing.assert_array_equal(net(torch.from_numpy(lidar).cuda()).cpu().numpy(), want_lidar)   # hashes were left clean
         c.check_errors(st.cuda_stream)
+    # an aborted forward must not poison the NEXT forward of the same (still compact) context even when the host has
+    # not looked at the error flag in between: its tail wiped the block hashes
+    st2 = torch.cuda.Stream()
+    with torch.cuda.stream(st2):
+        c2 = get_context(0, st2.cuda_stream)
+        c2.set_level_fractions(c2.LIDAR_FRACTIONS)
+        c2.reserve(len(lidar))
+        bad2 = net(torch.from_numpy(sparse).cuda())
+        good2 = net(torch.from_numpy(lidar).cuda())                                 # no check_errors in between
+        bad3 = net(torch.from_numpy(sparse).cuda())
+        good3 = net(torch.from_numpy(lidar).cuda())
+        with pytest.raises(SpsError) as ei:
+            c2.check_errors(st2.cuda_stream)
+        assert ei.value.code == _native.ERR_NOMEM
+        assert torch.isnan(bad2).all() and torch.isnan(bad3).all()
+        np.testing.assert_array_equal(good2.cpu().numpy(), want_lidar)
+        np.testing.assert_array_equal(good3.cpu().numpy(), want_lidar)
+        c2.set_level_fractions(None)
     # the engine's sequence loop retries by itself
     from sps_amd.engine import ScanEngine
     eng = ScanEngine(net, 0, streams=2, max_rows=len(lidar))
