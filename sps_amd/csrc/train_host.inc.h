@@ -48,6 +48,7 @@ struct sps_train {
   float *slab = nullptr;
   size_t slab_floats = 0;
   double *bn_part = nullptr, *bn_bpart = nullptr, *fin_part = nullptr;
+  float *bn_fin = nullptr, *bn_bfin = nullptr;  // per BN [2][BN_MAXC]: mean, invstd / scratch [2][BN_MAXC]: mean(dA), mean(dA xhat)
   float *batch_stats = nullptr;            // per BN [2][C] at 2 * ss_off-like offsets (same as c->ss layout)
   float *ones = nullptr, *zeros = nullptr;
   float *c0part = nullptr;
@@ -149,6 +150,11 @@ int train_reserve(sps_ctx *c) {
   TALLOC(t->bn_part, double, (size_t)s.bns.size() * BN_WG * 2 * BN_MAXC);
   TALLOC(t->bn_bpart, double, (size_t)BN_WG * 2 * BN_MAXC);
   TALLOC(t->fin_part, double, (size_t)BN_WG * 9);
+  for (const BnSpec &b : s.bns)
+    if (b.c < 8 || b.c > BN_MAXC || (b.c & (b.c - 1)))
+      return fail(SPS_ERR_INVALID, "training BatchNorm kernels need 8 <= C <= %d, a power of two (got %d)", BN_MAXC, b.c);
+  TALLOC(t->bn_fin, float, (size_t)s.bns.size() * 2 * BN_MAXC);
+  TALLOC(t->bn_bfin, float, (size_t)2 * BN_MAXC);
   TALLOC(t->batch_stats, float, s.ss_numel / 2 * 3);
   TALLOC(t->ones, float, 128);
   TALLOC(t->zeros, float, 128);
@@ -162,6 +168,8 @@ int train_reserve(sps_ctx *c) {
   t->arena_gen = c->arena_gen;
   return SPS_OK;
 }
+
+inline bool vec4_ok(const float *p, int ld) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0 && (ld & 3) == 0; }
 
 TView view_of(sps_train *t, const float *p) {
   for (const TView &v : t->views)
@@ -402,11 +410,14 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
     }
     if (rc != SPS_OK) return rc;
     double *part = t->bn_part + (size_t)bi * BN_WG * 2 * BN_MAXC;
-    hipLaunchKernelGGL(k_bn_stats, dim3(BN_WG), dim3(256), 0, st, z, cs.cout, c->counts + lo, cs.cout, part);
+    float *fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
+    if (!vec4_ok(z, cs.cout) || !vec4_ok(op.out.p, op.out.ld) || (op.res.p && !vec4_ok(op.res.p, op.res.ld)))
+      return fail(SPS_ERR_INVALID, "training BatchNorm operands must be 16-byte aligned (%s)", op.name);
+    hipLaunchKernelGGL(k_bn_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, z, cs.cout, c->counts + lo, cs.cout, part);
+    hipLaunchKernelGGL(k_bn_finish, dim3(1), dim3(BN_TPB), 0, st, part, c->counts + lo, cs.cout, fin, t->batch_stats + cs.ss_off / 2 * 3);
     const float *gamma = t->blob + bn.off, *beta = gamma + bn.c;
-    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * cs.cout, 256, 1024)), dim3(256), 0, st, z, cs.cout,
-                       c->counts + lo, cs.cout, part, gamma, beta, op.res.p, op.res.ld, op.relu, op.out.p, op.out.ld,
-                       t->batch_stats + cs.ss_off / 2 * 3);
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 2048)), dim3(256), 0, st, z, cs.cout,
+                       c->counts + lo, cs.cout, fin, gamma, beta, op.res.p, op.res.ld, op.relu, op.out.p, op.out.ld);
   }
   // final 1x1 conv + bias, slice, sigmoid (models.py:28-29)
   const ConvSpec &fs = s.convs[s.find_conv("final")];
@@ -455,13 +466,17 @@ int sps_train_backward(sps_ctx *c, const float *dscores, const float *scores, fl
     const BnSpec &bn = s.bns[bi];
     const int lo = op.out.level;
     const float *z = t->z[ci];
-    const double *part = t->bn_part + (size_t)bi * BN_WG * 2 * BN_MAXC;
+    const float *fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
+    if (!vec4_ok(op.out.g, op.out.ld) || (op.res.g && !vec4_ok(op.res.g, op.res.ld)))
+      return fail(SPS_ERR_INVALID, "training BatchNorm gradients must be 16-byte aligned (%s)", op.name);
     // BN (+ ReLU, + residual) backward: dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG), dim3(256), 0, st, op.out.g, op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout,
-                       c->counts + lo, cs.cout, part, t->bn_bpart);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * cs.cout, 256, 1024)), dim3(256), 0, st, op.out.g,
-                       op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, part, t->bn_bpart,
-                       t->blob + bn.off, t->dz, cs.cout, op.res.g, op.res.ld, t->grad + bn.off, t->grad + bn.off + bn.c);
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, op.out.g, op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout,
+                       c->counts + lo, cs.cout, fin, t->bn_bpart);
+    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(BN_TPB), 0, st, t->bn_bpart, c->counts + lo, cs.cout, t->bn_bfin, t->grad + bn.off,
+                       t->grad + bn.off + bn.c);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 2048)), dim3(256), 0, st, op.out.g,
+                       op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, fin, t->bn_bfin,
+                       t->blob + bn.off, t->dz, cs.cout, op.res.g, op.res.ld);
     int rc = SPS_OK;
     if (op.kind == T_CONV0) {
       const int nwg = 256;

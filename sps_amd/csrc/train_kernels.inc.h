@@ -39,156 +39,238 @@ __global__ void k_permute_weights(const float *__restrict__ W, int K, int cin, i
 // train-mode BatchNorm (ME.MinkowskiBatchNorm = nn.BatchNorm1d over the V active rows; resnet.py:93-94, eps = 1e-5)
 // ------------------------------------------------------------------------------------------
 constexpr int BN_WG = 256;     // partial-sum workgroups per reduction (fixed: the combine order is part of the result)
-constexpr int BN_MAXC = 96;
+constexpr int BN_MAXC = 64;    // C is 8, 16, 32 or 64 (a power of two: the host checks)
+constexpr int BN_TPB = 1024;   // 16 waves per workgroup: one workgroup per CU keeps 16 x 3 row streams in flight
 
-// pass 1: per workgroup, per channel: sum z and sum z^2 over its contiguous slice of rows (f64).
-// C is 8, 16, 32 or 64: a wave covers 64 / C rows x C channels per step (lane = rsub * C + c); the row sub-sums meet in
-// a fixed shuffle tree, the four waves in LDS in wave order -- the result does not depend on timing.
-__device__ inline void bn_wave_reduce(double &s0, double &s1, int C) {
-  for (int o = 32; o >= C; o >>= 1) {
-    s0 += __shfl_down(s0, o, 64);
-    s1 += __shfl_down(s1, o, 64);
+// Layout of the statistics passes: a lane owns FOUR channels (one float4 per row), a wave covers 64 / (C / 4) rows per
+// step, the 16 waves of a workgroup interleave over the workgroup's contiguous slice of rows.  Sums are f64; the row
+// sub-sums meet in a fixed shuffle tree, the waves in LDS in wave order, the BN_WG workgroups in index order (by the
+// LAST workgroup to finish, found with a ticket) -- the result does not depend on timing.
+struct BnAcc {
+  double a[4], b[4];
+};
+__device__ inline void bn_wave_reduce(BnAcc &s, int CV) {
+  for (int o = 32; o >= CV; o >>= 1)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s.a[j] += __shfl_down(s.a[j], o, 64);
+      s.b[j] += __shfl_down(s.b[j], o, 64);
+    }
+}
+// workgroup partial -> part[blockIdx][2][C]
+__device__ inline void bn_block_reduce(BnAcc &s, int C, double (*red)[16][BN_MAXC], double *__restrict__ part) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, CV = C >> 2;
+  bn_wave_reduce(s, CV);
+  if (lane < CV)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      red[0][wave][4 * lane + j] = s.a[j];
+      red[1][wave][4 * lane + j] = s.b[j];
+    }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += BN_TPB) {
+    const int w = i / C, cc = i - w * C;
+    double v = 0;
+    for (int q = 0; q < 16; ++q) v += red[w][q][cc];
+    part[((size_t)blockIdx.x * 2 + w) * C + cc] = v;
   }
 }
-__global__ __launch_bounds__(256) void k_bn_stats(const float *__restrict__ Z, int ld, const int *__restrict__ n_rows, int C,
-                                                   double *__restrict__ part /* [BN_WG][2][C] */) {
-  __shared__ double red[2][4][BN_MAXC];
+// k_bn_finish / k_bn_bwd_finish (one workgroup; a "last workgroup done" ticket inside the statistics kernel was measured:
+// the device-scope fence it needs writes back the XCD's L2 and cost 70 us per launch): sum the BN_WG partials of channel c
+// in index order.  1024 / C threads per channel take contiguous runs of partials, the runs meet in LDS in run order.
+// Returns the two sums in (t0, t1) for threads < C.
+__device__ inline void bn_combine(const double *__restrict__ vp, int C, double (*red)[16][BN_MAXC], double &t0, double &t1) {
+  double *r0 = &red[0][0][0], *r1 = &red[1][0][0];  // [BN_TPB / C runs][C] each (1024 doubles = the size of red[w])
+  const int c = threadIdx.x % C, run = threadIdx.x / C, per = BN_WG / (BN_TPB / C);
+  double s0 = 0, s1 = 0;
+  for (int w = run * per; w < (run + 1) * per; ++w) {
+    s0 += vp[((size_t)w * 2 + 0) * C + c];
+    s1 += vp[((size_t)w * 2 + 1) * C + c];
+  }
+  r0[run * C + c] = s0;
+  r1[run * C + c] = s1;
+  __syncthreads();
+  t0 = t1 = 0;
+  if (threadIdx.x < (unsigned)C)
+    for (int q = 0; q < BN_TPB / C; ++q) {
+      t0 += r0[q * C + threadIdx.x];
+      t1 += r1[q * C + threadIdx.x];
+    }
+}
+
+// pass 1: per channel sum z and sum z^2 (k_bn_stats) -> fin[0][c] = mean, fin[1][c] = invstd + the batch statistics the
+// host folds into running_mean / running_var: mean, biased var, unbiased var (k_bn_finish)
+__global__ __launch_bounds__(BN_TPB) void k_bn_stats(const float *__restrict__ Z, int ld, const int *__restrict__ n_rows, int C,
+                                                      double *__restrict__ part /* [BN_WG][2][C] */) {
+  __shared__ double red[2][16][BN_MAXC];
   const int n = *n_rows;
   const int per = (n + BN_WG - 1) / BN_WG;
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rpw = 64 / C, c = lane % C, rsub = lane / C;   // rows per wave step
-  double s0 = 0, s1 = 0;
-  for (int r = r0 + wave * rpw + rsub; r < r1; r += 4 * rpw) {
-    const double v = (double)Z[(size_t)r * ld + c];
-    s0 += v;
-    s1 += v * v;
+  const int CV = C >> 2, rpw = 64 / CV, cv = lane % CV, rsub = lane / CV;
+  BnAcc s = {};
+  for (int r = r0 + wave * rpw + rsub; r < r1; r += 16 * rpw) {
+    const float4 v = *reinterpret_cast<const float4 *>(Z + (size_t)r * ld + 4 * cv);
+    const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s.a[j] += (double)e[j];
+      s.b[j] += (double)e[j] * (double)e[j];
+    }
   }
-  bn_wave_reduce(s0, s1, C);
-  if (lane < C) {
-    red[0][wave][c] = s0;
-    red[1][wave][c] = s1;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    const int w = i / C, cc = i - w * C;
-    part[((size_t)blockIdx.x * 2 + w) * C + cc] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
-  }
+  bn_block_reduce(s, C, red, part);
 }
-
-// combine the BN_WG partials in index order -> mean / invstd of channel c (every workgroup of the consumer recomputes
-// them: BN_WG * C adds, cheaper than a launch).  Also the batch statistics the host folds into running_mean / _var.
-__device__ inline void bn_finish(const double *__restrict__ part, int C, int n, int c, float &mean, float &invstd,
-                                 float *__restrict__ batch_stats /* [3][C]: mean, biased var, unbiased var; or null */) {
-  double s0 = 0, s1 = 0;
-  for (int w = 0; w < BN_WG; ++w) {
-    s0 += part[((size_t)w * 2 + 0) * C + c];
-    s1 += part[((size_t)w * 2 + 1) * C + c];
-  }
-  const double m = n > 0 ? s0 / n : 0.0;
-  double var = n > 0 ? s1 / n - m * m : 0.0;
-  if (var < 0) var = 0;
-  mean = (float)m;
-  invstd = (float)(1.0 / sqrt(var + 1e-5));
-  if (batch_stats) {
+__global__ __launch_bounds__(BN_TPB) void k_bn_finish(const double *__restrict__ part, const int *__restrict__ n_rows, int C,
+                                                       float *__restrict__ fin /* [2][BN_MAXC] */,
+                                                       float *__restrict__ batch_stats /* [3][C] */) {
+  __shared__ double red[2][16][BN_MAXC];
+  const int n = *n_rows;
+  double s0, s1;
+  bn_combine(part, C, red, s0, s1);
+  if (threadIdx.x < (unsigned)C) {
+    const int c = threadIdx.x;
+    const double m = n > 0 ? s0 / n : 0.0;
+    double var = n > 0 ? s1 / n - m * m : 0.0;
+    if (var < 0) var = 0;
+    fin[c] = (float)m;
+    fin[BN_MAXC + c] = (float)(1.0 / sqrt(var + 1e-5));
     batch_stats[c] = (float)m;
     batch_stats[C + c] = (float)var;
     batch_stats[2 * C + c] = (float)(n > 1 ? var * ((double)n / (double)(n - 1)) : var);  // what running_var accumulates
   }
 }
 
-// pass 2: y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] )
+// pass 2: y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] ), one float4 per thread step
 __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, int ldz, const int *__restrict__ n_rows, int C,
-                                                   const double *__restrict__ part, const float *__restrict__ gamma,
+                                                   const float *__restrict__ fin, const float *__restrict__ gamma,
                                                    const float *__restrict__ beta, const float *__restrict__ res, int ldr,
-                                                   int relu, float *__restrict__ Y, int ldy, float *__restrict__ batch_stats) {
+                                                   int relu, float *__restrict__ Y, int ldy) {
   __shared__ float sc[BN_MAXC], sh[BN_MAXC];
   const int n = *n_rows;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float mean, invstd;
-    bn_finish(part, C, n, c, mean, invstd, blockIdx.x == 0 ? batch_stats : nullptr);
+    const float mean = fin[c], invstd = fin[BN_MAXC + c];
     sc[c] = invstd * gamma[c];
     sh[c] = beta[c] - mean * invstd * gamma[c];
   }
   __syncthreads();
-  const int64_t total = (int64_t)n * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
-    float y = Z[(size_t)r * ldz + c] * sc[c] + sh[c];
-    if (res) y += res[(size_t)r * ldr + c];
-    if (relu) y = fmaxf(y, 0.f);
-    Y[(size_t)r * ldy + c] = y;
+  const int lcv = __ffs(C) - 3, CV = C >> 2;
+  const int total = n * CV;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i >> lcv, c = (i & (CV - 1)) << 2;
+    const float4 z = *reinterpret_cast<const float4 *>(Z + (size_t)r * ldz + c);
+    float y[4] = {z.x * sc[c] + sh[c], z.y * sc[c + 1] + sh[c + 1], z.z * sc[c + 2] + sh[c + 2], z.w * sc[c + 3] + sh[c + 3]};
+    if (res) {
+      const float4 q = *reinterpret_cast<const float4 *>(res + (size_t)r * ldr + c);
+      y[0] += q.x, y[1] += q.y, y[2] += q.z, y[3] += q.w;
+    }
+    if (relu)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = fmaxf(y[j], 0.f);
+    *reinterpret_cast<float4 *>(Y + (size_t)r * ldy + c) = make_float4(y[0], y[1], y[2], y[3]);
   }
 }
 
 // backward pass 1: dA = dY * (Y > 0 if relu); per channel sum dA and sum dA * xhat (xhat = (z - mean) * invstd)
-__global__ __launch_bounds__(256) void k_bn_bwd_stats(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
-                                                       int relu, const float *__restrict__ Z, int ldz,
-                                                       const int *__restrict__ n_rows, int C, const double *__restrict__ part,
-                                                       double *__restrict__ bpart /* [BN_WG][2][C] */) {
-  __shared__ double red[2][4][BN_MAXC];
-  __shared__ float mean_s[BN_MAXC], inv_s[BN_MAXC];
+// (k_bn_bwd_stats) -> dbeta, dgamma and bfin[0][c] = mean(dA), bfin[1][c] = mean(dA * xhat) (k_bn_bwd_finish)
+__global__ __launch_bounds__(BN_TPB) void k_bn_bwd_stats(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
+                                                          int relu, const float *__restrict__ Z, int ldz,
+                                                          const int *__restrict__ n_rows, int C, const float *__restrict__ fin,
+                                                          double *__restrict__ bpart /* [BN_WG][2][C] */) {
+  __shared__ double red[2][16][BN_MAXC];
   const int n = *n_rows;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) bn_finish(part, C, n, c, mean_s[c], inv_s[c], nullptr);
-  __syncthreads();
   const int per = (n + BN_WG - 1) / BN_WG;
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int rpw = 64 / C, c = lane % C, rsub = lane / C;
-  double s0 = 0, s1 = 0;
-  for (int r = r0 + wave * rpw + rsub; r < r1; r += 4 * rpw) {
-    float g = dY[(size_t)r * ldg + c];
-    if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
-    const float xh = (Z[(size_t)r * ldz + c] - mean_s[c]) * inv_s[c];
-    s0 += (double)g;
-    s1 += (double)g * (double)xh;
+  const int CV = C >> 2, rpw = 64 / CV, cv = lane % CV, rsub = lane / CV;
+  float mean[4], inv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    mean[j] = fin[4 * cv + j];
+    inv[j] = fin[BN_MAXC + 4 * cv + j];
   }
-  bn_wave_reduce(s0, s1, C);
-  if (lane < C) {
-    red[0][wave][c] = s0;
-    red[1][wave][c] = s1;
+  BnAcc s = {};
+  for (int r = r0 + wave * rpw + rsub; r < r1; r += 16 * rpw) {
+    const float4 gv = *reinterpret_cast<const float4 *>(dY + (size_t)r * ldg + 4 * cv);
+    const float4 zv = *reinterpret_cast<const float4 *>(Z + (size_t)r * ldz + 4 * cv);
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float z[4] = {zv.x, zv.y, zv.z, zv.w};
+    if (relu) {
+      const float4 yv = *reinterpret_cast<const float4 *>(Y + (size_t)r * ldy + 4 * cv);
+      const float y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(y[j] > 0.f)) g[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (z[j] - mean[j]) * inv[j];
+      s.a[j] += (double)g[j];
+      s.b[j] += (double)g[j] * (double)xh;
+    }
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
-    const int w = i / C, cc = i - w * C;
-    bpart[((size_t)blockIdx.x * 2 + w) * C + cc] = red[w][0][cc] + red[w][1][cc] + red[w][2][cc] + red[w][3][cc];
+  bn_block_reduce(s, C, red, bpart);
+}
+__global__ __launch_bounds__(BN_TPB) void k_bn_bwd_finish(const double *__restrict__ bpart, const int *__restrict__ n_rows, int C,
+                                                           float *__restrict__ bfin /* [2][BN_MAXC] */, float *__restrict__ dgamma,
+                                                           float *__restrict__ dbeta) {
+  __shared__ double red[2][16][BN_MAXC];
+  const int n = *n_rows;
+  double s0, s1;
+  bn_combine(bpart, C, red, s0, s1);
+  if (threadIdx.x < (unsigned)C) {
+    const int c = threadIdx.x;
+    dbeta[c] = (float)s0;
+    dgamma[c] = (float)s1;
+    bfin[c] = n > 0 ? (float)(s0 / n) : 0.f;
+    bfin[BN_MAXC + c] = n > 0 ? (float)(s1 / n) : 0.f;
   }
 }
 
-// backward pass 2: dZ = gamma * invstd * (dA - mean(dA) - xhat * mean(dA * xhat)); dgamma = sum dA xhat, dbeta = sum dA;
+// backward pass 2: dZ = gamma * invstd * (dA - mean(dA) - xhat * mean(dA * xhat));
 // the masked gradient dA is also ADDED to dres (the gradient of the residual operand), when given.
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
                                                        int relu, const float *__restrict__ Z, int ldz,
-                                                       const int *__restrict__ n_rows, int C, const double *__restrict__ part,
-                                                       const double *__restrict__ bpart, const float *__restrict__ gamma,
-                                                       float *__restrict__ dZ, int lddz, float *__restrict__ dres, int lddr,
-                                                       float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                       const int *__restrict__ n_rows, int C, const float *__restrict__ fin,
+                                                       const float *__restrict__ bfin, const float *__restrict__ gamma,
+                                                       float *__restrict__ dZ, int lddz, float *__restrict__ dres, int lddr) {
   __shared__ float mean_s[BN_MAXC], inv_s[BN_MAXC], k1_s[BN_MAXC], k2_s[BN_MAXC], gi_s[BN_MAXC];
   const int n = *n_rows;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    bn_finish(part, C, n, c, mean_s[c], inv_s[c], nullptr);
-    double s0 = 0, s1 = 0;
-    for (int w = 0; w < BN_WG; ++w) {
-      s0 += bpart[((size_t)w * 2 + 0) * C + c];
-      s1 += bpart[((size_t)w * 2 + 1) * C + c];
-    }
-    if (blockIdx.x == 0) {
-      dbeta[c] = (float)s0;
-      dgamma[c] = (float)s1;
-    }
-    k1_s[c] = n > 0 ? (float)(s0 / n) : 0.f;
-    k2_s[c] = n > 0 ? (float)(s1 / n) : 0.f;
-    gi_s[c] = gamma[c] * inv_s[c];
+    mean_s[c] = fin[c];
+    inv_s[c] = fin[BN_MAXC + c];
+    k1_s[c] = bfin[c];
+    k2_s[c] = bfin[BN_MAXC + c];
+    gi_s[c] = gamma[c] * fin[BN_MAXC + c];
   }
   __syncthreads();
-  const int64_t total = (int64_t)n * C;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int r = (int)(i / C), c = (int)(i - (int64_t)r * C);
-    float g = dY[(size_t)r * ldg + c];
-    if (relu && !(Y[(size_t)r * ldy + c] > 0.f)) g = 0.f;
-    const float xh = (Z[(size_t)r * ldz + c] - mean_s[c]) * inv_s[c];
-    dZ[(size_t)r * lddz + c] = gi_s[c] * (g - k1_s[c] - xh * k2_s[c]);
-    if (dres) dres[(size_t)r * lddr + c] += g;
+  const int lcv = __ffs(C) - 3, CV = C >> 2;
+  const int total = n * CV;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int r = i >> lcv, c = (i & (CV - 1)) << 2;
+    const float4 gv = *reinterpret_cast<const float4 *>(dY + (size_t)r * ldg + c);
+    const float4 zv = *reinterpret_cast<const float4 *>(Z + (size_t)r * ldz + c);
+    float g[4] = {gv.x, gv.y, gv.z, gv.w};
+    const float z[4] = {zv.x, zv.y, zv.z, zv.w};
+    if (relu) {
+      const float4 yv = *reinterpret_cast<const float4 *>(Y + (size_t)r * ldy + c);
+      const float y[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (!(y[j] > 0.f)) g[j] = 0.f;
+    }
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (z[j] - mean_s[c + j]) * inv_s[c + j];
+      o[j] = gi_s[c + j] * (g[j] - k1_s[c + j] - xh * k2_s[c + j]);
+    }
+    *reinterpret_cast<float4 *>(dZ + (size_t)r * lddz + c) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres) {
+      float4 *dp = reinterpret_cast<float4 *>(dres + (size_t)r * lddr + c);
+      float4 d = *dp;
+      d.x += g[0], d.y += g[1], d.z += g[2], d.w += g[3];
+      *dp = d;
+    }
   }
 }
 
