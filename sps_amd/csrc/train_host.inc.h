@@ -327,19 +327,22 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
     w.nbr = L.down;
     w.tmask = L.tmdown;
   }
-  // rows are cut into chunks (partial sums added in chunk order): enough waves for the fine levels, few for the coarse
-  // enough waves to fill the chip (~16 k) whatever the layer's K x tile count; every wave walks its chunk's tiles as a
-  // chain of dependent loads, so short chunks also bound the launch's duration
-  int nchunk = (int)std::min<int64_t>(128, std::max<int64_t>(4, 16384 / ((int64_t)K * w.MT * w.NT)));
+  if (w.ldn % 16) return fail(SPS_ERR_INVALID, "wgrad: level capacity %lld is not a multiple of 16", (long long)w.ldn);
+  w.dW = dW;
+  // rows are cut into chunks of tiles, one per wave, 16 waves per workgroup (partial sums added in wave, then workgroup
+  // order): enough waves to fill the chip (~16 k) whatever the layer's K x tile count, and at least ~8 tiles per chunk;
+  // every wave walks its chunk as a chain of dependent loads, so short chunks also bound the launch's duration
+  const int64_t want = std::min<int64_t>(128, std::max<int64_t>(WG_WAVES, 16384 / ((int64_t)K * w.MT * w.NT)));
+  int nwg = (int)((want + WG_WAVES - 1) / WG_WAVES);
   const int64_t tiles_cap = (c->capl[level_rows] / 16);
-  while (nchunk > 4 && (int64_t)nchunk * 8 > tiles_cap) nchunk >>= 1;   // at least ~8 tiles per chunk
-  while ((size_t)K * w.MT * w.NT * nchunk * 256 > t->slab_floats && nchunk > 1) nchunk >>= 1;
-  if ((size_t)K * w.MT * w.NT * nchunk * 256 > t->slab_floats) return fail(SPS_ERR_INVALID, "wgrad slab too small");
-  w.nchunk = nchunk;
-  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)((nchunk + 3) / 4), (unsigned)K, (unsigned)(w.MT * w.NT)), dim3(256), 0, st, w);
-  const int total = K * cin * cout;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, t->slab, K, cin, cout,
-                     w.MT, w.NT, nchunk, dW);
+  while (nwg > 1 && (int64_t)nwg * WG_WAVES * 8 > tiles_cap) nwg >>= 1;
+  while ((size_t)K * w.MT * w.NT * nwg * 256 > t->slab_floats && nwg > 1) nwg >>= 1;
+  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)nwg, (unsigned)K, (unsigned)(w.MT * w.NT)), dim3(WG_WAVES * 64), 0, st, w);
+  if (nwg > 1) {
+    const int total = K * cin * cout;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, t->slab, K, cin, cout,
+                       w.MT, w.NT, nwg, dW);
+  }
   return SPS_OK;
 }
 

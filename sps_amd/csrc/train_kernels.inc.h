@@ -278,11 +278,15 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 // weight gradient of a sparse convolution: dW[k][ci][co] = sum over the pairs (i, o) of offset k of x[i][ci] * dz[o][co]
 // ------------------------------------------------------------------------------------------
 // One wave = one 16 x 16 tile (mt, nt) of dW[k] over one chunk of the map's rows; MFMA 16x16x4 with the PAIRS as the
-// contraction dimension: lane (m, q) feeds A[m][q] = x[i_q][16 mt + m] and B[q][n] = dz[o_q][16 nt + n] for the four
-// rows o = o0 + q of a step.  Tiles of 16 rows whose mask lacks offset k are skipped.
+// contraction dimension: lane (m, q) feeds A[m][q] = x[i][16 mt + m] and B[q][n] = dz[o][16 nt + n] for row 4 q + s of the
+// tile in step s (so a lane's four map entries are ONE 16-byte load).  Tiles of 16 rows whose mask lacks offset k are
+// skipped: the wave first turns the mask words of (up to) 64 tiles into a ballot, then walks the set bits two tiles at a
+// time, all loads of both tiles issued together -- the chain per pair of tiles is map entry -> operand rows -> MFMA.
 //   gather_b = 0: i = nbr[k][o], o = row      (3^4 convs and stride-2 convs: the map gathers the INPUT)
 //   gather_b = 1: i = row, o = nbr[k][row]    (transposed convs: the `down` table of the coarse level lists the OUTPUT rows)
-// Partials go to slab[((k * MT + mt) * NT + nt) * nchunk + chunk][16][16]; k_wgrad_reduce adds the chunks in order.
+// The 16 waves of a workgroup take 16 consecutive chunks and add their tiles in LDS in wave order; with one workgroup per
+// (k, tile) the sum IS dW, otherwise it goes to slab[((k * MT + mt) * NT + nt) * nwg + wg][16][16] and k_wgrad_reduce adds
+// the workgroups in order.
 struct WgradArgs {
   const float *x;   // [*, ldx] operand indexed by i
   const float *dz;  // [*, ldz] operand indexed by o
@@ -290,11 +294,36 @@ struct WgradArgs {
   const uint32_t *tmask;
   const int *n_rows;  // rows of the map (device count)
   float *slab;
-  int64_t ldn;
-  int ldx, ldz, K, cin, cout, MT, NT, nchunk, gather_b;
+  float *dW;          // [K][cin][cout]
+  int64_t ldn;        // multiple of 16 (the host checks): a tile's map entries are in range and 16-byte aligned
+  int ldx, ldz, K, cin, cout, MT, NT, gather_b;
 };
+constexpr int WG_WAVES = 16;
 
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+struct WgradTile {
+  float av[4], bv[4];
+};
+__device__ inline void wgrad_load(const WgradArgs &a, int t, int k, int n, int q, int ca, int cb, bool va, bool vb, WgradTile &w) {
+  const int row0 = t * 16 + 4 * q;
+  int other[4] = {row0, row0 + 1, row0 + 2, row0 + 3};
+  if (a.nbr && t >= 0) {
+    const int4 e = *reinterpret_cast<const int4 *>(a.nbr + (size_t)k * a.ldn + row0);
+    other[0] = e.x, other[1] = e.y, other[2] = e.z, other[3] = e.w;
+  }
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int row = row0 + s;
+    const bool in = t >= 0 && row < n;
+    const int i = a.gather_b ? row : other[s];
+    const int o = a.gather_b ? other[s] : row;
+    const bool ok = in && i >= 0 && o >= 0;
+    w.av[s] = (ok && va) ? a.x[(size_t)i * a.ldx + ca] : 0.f;
+    w.bv[s] = (ok && vb) ? a.dz[(size_t)o * a.ldz + cb] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
+  __shared__ float red[WG_WAVES][256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int n = *a.n_rows;
@@ -302,46 +331,60 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
   const int k = blockIdx.y;
   const int tile_id = blockIdx.z;  // mt * NT + nt
   const int mt = tile_id / a.NT, nt = tile_id - mt * a.NT;
-  const int chunk = blockIdx.x * 4 + wave;
-  if (chunk >= a.nchunk) return;
-  const int per = (ntiles + a.nchunk - 1) / a.nchunk;
+  const int nchunk = (int)gridDim.x * WG_WAVES;
+  const int chunk = blockIdx.x * WG_WAVES + wave;
+  const int per = (ntiles + nchunk - 1) / nchunk;
   const int t0 = chunk * per, t1 = min(ntiles, t0 + per);
   const int ca = mt * 16 + m, cb = nt * 16 + m;
   const bool va = ca < a.cin, vb = cb < a.cout;
+  const int kw = k / 27, kb = k % 27;  // one mask word per time slice (27 offsets); K = 8 maps: word 0
   floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
-  for (int t = t0; t < t1; ++t) {
-    if (a.tmask) {
-      const uint32_t w = a.tmask[(size_t)t * 4 + k / 27];  // one word per time slice (27 offsets); K = 8 maps: word 0
-      if (!((w >> (k % 27)) & 1u)) continue;
-    }
+  for (int tb = t0; tb < t1; tb += 64) {
+    const int tl = tb + lane;
+    bool present = tl < t1;
+    if (present && a.tmask) present = (a.tmask[(size_t)tl * 4 + kw] >> kb) & 1u;
+    uint64_t bm = __ballot(present);
+    while (bm) {
+      const int ta = tb + __builtin_ctzll(bm);
+      bm &= bm - 1;
+      const int tc = bm ? tb + __builtin_ctzll(bm) : -1;
+      bm &= bm - 1;  // 0 & anything = 0
+      WgradTile u, v;
+      wgrad_load(a, ta, k, n, q, ca, cb, va, vb, u);
+      wgrad_load(a, tc, k, n, q, ca, cb, va, vb, v);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int row = t * 16 + 4 * s + q;
-      int other = row < n ? row : -1;
-      if (a.nbr && row < n) other = a.nbr[(size_t)k * a.ldn + row];
-      const int i = a.gather_b ? (row < n ? row : -1) : other;
-      const int o = a.gather_b ? other : (row < n ? row : -1);
-      const bool ok = i >= 0 && o >= 0;
-      const float av = (ok && va) ? a.x[(size_t)i * a.ldx + ca] : 0.f;
-      const float bv = (ok && vb) ? a.dz[(size_t)o * a.ldz + cb] : 0.f;
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u.av[s], u.bv[s], acc, 0, 0, 0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.av[s], v.bv[s], acc, 0, 0, 0);
     }
   }
   // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
-  float *dst = a.slab + (((size_t)k * a.MT * a.NT + tile_id) * a.nchunk + chunk) * 256;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) dst[(q * 4 + i) * 16 + m] = acc[i];
+  for (int i = 0; i < 4; ++i) red[wave][(q * 4 + i) * 16 + m] = acc[i];
+  __syncthreads();
+  if (threadIdx.x < 256) {
+    const int e = threadIdx.x;
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < WG_WAVES; ++w) sum += red[w][e];
+    if (gridDim.x == 1) {
+      const int ci = mt * 16 + (e >> 4), co = nt * 16 + (e & 15);
+      if (ci < a.cin && co < a.cout) a.dW[((size_t)k * a.cin + ci) * a.cout + co] = sum;
+    } else {
+      a.slab[(((size_t)k * a.MT * a.NT + tile_id) * gridDim.x + blockIdx.x) * 256 + e] = sum;
+    }
+  }
 }
 
-__global__ void k_wgrad_reduce(const float *__restrict__ slab, int K, int cin, int cout, int MT, int NT, int nchunk,
+__global__ void k_wgrad_reduce(const float *__restrict__ slab, int K, int cin, int cout, int MT, int NT, int nwg,
                                float *__restrict__ dW /* [K][cin][cout] */) {
   const int total = K * cin * cout;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int co = i % cout, ci = (i / cout) % cin, k = i / (cout * cin);
     const int mt = ci >> 4, nt = co >> 4;
-    const float *src = slab + (((size_t)k * MT * NT + mt * NT + nt) * nchunk) * 256 + (ci & 15) * 16 + (co & 15);
+    const float *src = slab + (((size_t)k * MT * NT + mt * NT + nt) * nwg) * 256 + (ci & 15) * 16 + (co & 15);
     float s = 0.f;
-    for (int c = 0; c < nchunk; ++c) s += src[(size_t)c * 256];
+    for (int c = 0; c < nwg; ++c) s += src[(size_t)c * 256];
     dW[i] = s;
   }
 }
