@@ -52,6 +52,8 @@ struct sps_train {
   float *batch_stats = nullptr;            // per BN [2][C] at 2 * ss_off-like offsets (same as c->ss layout)
   float *ones = nullptr, *zeros = nullptr;
   float *c0part = nullptr;
+  PermDesc *perm = nullptr;                // operand table of k_permute_weights (one launch per step)
+  int n_perm = 0, perm_blocks = 0;
   long long *vacc = nullptr;
   // gradient views of the context's feature buffers, in the order of feat_list()
   std::vector<TView> views;
@@ -67,6 +69,8 @@ void train_free(sps_train *t) {
   t->cap = 0;
   t->have_forward = false;
 }
+
+constexpr int C0_WG = 1024;  // workgroups (x 4 waves, one row at a time each) of k_conv0_wgrad
 
 #define TALLOC(ptr, type, count)                                                                    \
   do {                                                                                              \
@@ -158,7 +162,32 @@ int train_reserve(sps_ctx *c) {
   TALLOC(t->batch_stats, float, s.ss_numel / 2 * 3);
   TALLOC(t->ones, float, 128);
   TALLOC(t->zeros, float, 128);
-  TALLOC(t->c0part, float, (size_t)256 * 1000);
+  TALLOC(t->c0part, float, (size_t)C0_WG * 1000);
+  {
+    std::vector<PermDesc> pd;
+    int blk = 0;
+    for (size_t i = 0; i < s.convs.size(); ++i) {
+      const ConvSpec &cs = s.convs[i];
+      if (cs.cin == 1 || cs.name == "final") continue;
+      // forward operand, then the data-gradient operand: symmetric 3^4 maps mirror the offset; stride / transposed / 1x1 maps keep it
+      const int modes[2] = {0, cs.K == 81 ? 1 : 2};
+      for (int mode : modes) {
+        const int tot = mode == 0 ? cs.K * (cs.cin / 4) * ((cs.cout + 15) / 16) * 64 : cs.K * (cs.cout / 4) * ((cs.cin + 15) / 16) * 64;
+        PermDesc d{};
+        d.w_off = cs.w_off;
+        d.dst_off = mode == 0 ? t->wu_off[i] : t->wut_off[i];
+        d.K = cs.K, d.cin = cs.cin, d.cout = cs.cout, d.mode = mode;
+        d.blk0 = blk;
+        d.nblk = std::min(64, (tot + 255) / 256);
+        blk += d.nblk;
+        pd.push_back(d);
+      }
+    }
+    t->n_perm = (int)pd.size();
+    t->perm_blocks = blk;
+    TALLOC(t->perm, PermDesc, pd.size());
+    HIP_TRY(hipMemcpy(t->perm, pd.data(), pd.size() * sizeof(PermDesc), hipMemcpyHostToDevice));
+  }
   TALLOC(t->vacc, long long, cap);
   std::vector<float> one(128, 1.f);
   HIP_TRY(hipMemcpy(t->ones, one.data(), 128 * sizeof(float), hipMemcpyHostToDevice));
@@ -332,7 +361,7 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
   // rows are cut into chunks of tiles, one per wave, 16 waves per workgroup (partial sums added in wave, then workgroup
   // order): enough waves to fill the chip (~16 k) whatever the layer's K x tile count, and at least ~8 tiles per chunk;
   // every wave walks its chunk as a chain of dependent loads, so short chunks also bound the launch's duration
-  const int64_t want = std::min<int64_t>(128, std::max<int64_t>(WG_WAVES, 16384 / ((int64_t)K * w.MT * w.NT)));
+  const int64_t want = std::min<int64_t>(1024, std::max<int64_t>(WG_WAVES, 16384 / ((int64_t)K * w.MT * w.NT)));
   int nwg = (int)((want + WG_WAVES - 1) / WG_WAVES);
   const int64_t tiles_cap = (c->capl[level_rows] / 16);
   while (nwg > 1 && (int64_t)nwg * WG_WAVES * 8 > tiles_cap) nwg >>= 1;
@@ -340,8 +369,7 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
   hipLaunchKernelGGL(k_wgrad, dim3((unsigned)nwg, (unsigned)K, (unsigned)(w.MT * w.NT)), dim3(WG_WAVES * 64), 0, st, w);
   if (nwg > 1) {
     const int total = K * cin * cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)std::min(1024, (total + 255) / 256)), dim3(256), 0, st, t->slab, K, cin, cout,
-                       w.MT, w.NT, nwg, dW);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, t->slab, K, cin, cout, w.MT, w.NT, nwg, dW);
   }
   return SPS_OK;
 }
@@ -382,19 +410,7 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
   t->have_forward = false;
   HIP_TRY(hipMemcpyAsync(t->blob, params_dev, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
   // operands of this step's weights
-  for (size_t i = 0; i < s.convs.size(); ++i) {
-    const ConvSpec &cs = s.convs[i];
-    if (cs.cin == 1 || cs.name == "final") continue;
-    const bool up = cs.name.compare(0, 6, "convtr") == 0;
-    const int tot_f = cs.K * (cs.cin / 4) * ((cs.cout + 15) / 16) * 64, tot_b = cs.K * (cs.cout / 4) * ((cs.cin + 15) / 16) * 64;
-    hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)std::min(512, (tot_f + 255) / 256)), dim3(256), 0, st, t->blob + cs.w_off,
-                       cs.K, cs.cin, cs.cout, 0, t->wu + t->wu_off[i]);
-    // data gradient: symmetric 3^4 maps mirror the offset; stride / transposed / 1x1 maps keep it
-    const int mode = cs.K == 81 ? 1 : 2;
-    (void)up;
-    hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)std::min(512, (tot_b + 255) / 256)), dim3(256), 0, st, t->blob + cs.w_off,
-                       cs.K, cs.cin, cs.cout, mode, t->wut + t->wut_off[i]);
-  }
+  hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)t->perm_blocks), dim3(256), 0, st, t->perm, t->n_perm, t->blob, t->wu, t->wut);
   const auto ops = train_ops(c);
   for (const TOp &op : ops) {
     const int ci = s.find_conv(op.name);
@@ -482,9 +498,8 @@ int sps_train_backward(sps_ctx *c, const float *dscores, const float *scores, fl
                        t->blob + bn.off, t->dz, cs.cout, op.res.g, op.res.ld);
     int rc = SPS_OK;
     if (op.kind == T_CONV0) {
-      const int nwg = 256;
-      hipLaunchKernelGGL(k_conv0_wgrad, dim3(nwg), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
-      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(4), dim3(256), 0, st, t->c0part, nwg, t->grad + cs.w_off);
+      hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
+      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(32), dim3(256), 0, st, t->c0part, C0_WG, t->grad + cs.w_off);
       continue;  // the input feature is a constant: no data gradient
     }
     // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated

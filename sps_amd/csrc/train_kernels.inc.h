@@ -13,11 +13,22 @@
 //   mode 0: W'[k][ci][co] = W[k][ci][co]            (forward operand; C_in' = C_in,  C_out' = C_out)
 //   mode 1: W'[k][co][ci] = W[K - 1 - k][ci][co]    (data gradient over a symmetric 3^4 map; C_in' = C_out, C_out' = C_in)
 //   mode 2: W'[k][co][ci] = W[k][ci][co]            (data gradient over a stride map: same octant, transposed)
-__global__ void k_permute_weights(const float *__restrict__ W, int K, int cin, int cout, int mode, float *__restrict__ Wu) {
+struct PermDesc {   // one operand of one conv; its workgroups are [blk0, blk0 + nblk) of the launch
+  int64_t w_off, dst_off;
+  int K, cin, cout, mode, blk0, nblk;
+};
+__global__ __launch_bounds__(256) void k_permute_weights(const PermDesc *__restrict__ descs, int ndesc, const float *__restrict__ blob,
+                                                          float *__restrict__ wu, float *__restrict__ wut) {
+  int d = 0;
+  while (d + 1 < ndesc && (int)blockIdx.x >= descs[d + 1].blk0) ++d;
+  const PermDesc pd = descs[d];
+  const float *__restrict__ W = blob + pd.w_off;
+  float *__restrict__ Wu = (pd.mode == 0 ? wu : wut) + pd.dst_off;
+  const int K = pd.K, cin = pd.cin, cout = pd.cout, mode = pd.mode;
   const int cin2 = mode == 0 ? cin : cout, cout2 = mode == 0 ? cout : cin;
   const int upk = cin2 / 4, NT = (cout2 + 15) / 16;
   const int total = K * upk * NT * 64;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  for (int i = ((int)blockIdx.x - pd.blk0) * blockDim.x + threadIdx.x; i < total; i += pd.nblk * blockDim.x) {
     const int s = i & 3, n = (i >> 2) & 15;
     const int rest = i >> 6;
     const int nt = rest % NT, u = rest / NT;
@@ -44,8 +55,8 @@ constexpr int BN_TPB = 1024;   // 16 waves per workgroup: one workgroup per CU k
 
 // Layout of the statistics passes: a lane owns FOUR channels (one float4 per row), a wave covers 64 / (C / 4) rows per
 // step, the 16 waves of a workgroup interleave over the workgroup's contiguous slice of rows.  Sums are f64; the row
-// sub-sums meet in a fixed shuffle tree, the waves in LDS in wave order, the BN_WG workgroups in index order (by the
-// LAST workgroup to finish, found with a ticket) -- the result does not depend on timing.
+// sub-sums meet in a fixed shuffle tree, the waves in LDS in wave order, the BN_WG workgroups in index order (in the
+// one-workgroup finish kernels) -- the result does not depend on timing.
 struct BnAcc {
   double a[4], b[4];
 };
@@ -376,16 +387,26 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
   }
 }
 
-__global__ void k_wgrad_reduce(const float *__restrict__ slab, int K, int cin, int cout, int MT, int NT, int nwg,
-                               float *__restrict__ dW /* [K][cin][cout] */) {
+// 32 outputs per workgroup; 8 threads per output add every 8th workgroup partial (ascending), then meet in LDS in order
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slab, int K, int cin, int cout, int MT, int NT, int nwg,
+                                                       float *__restrict__ dW /* [K][cin][cout] */) {
+  __shared__ float red[8][32];
   const int total = K * cin * cout;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+  const int j = threadIdx.x >> 5, i = blockIdx.x * 32 + (threadIdx.x & 31);
+  float s = 0.f;
+  if (i < total) {
     const int co = i % cout, ci = (i / cout) % cin, k = i / (cout * cin);
     const int mt = ci >> 4, nt = co >> 4;
     const float *src = slab + (((size_t)k * MT * NT + mt * NT + nt) * nwg) * 256 + (ci & 15) * 16 + (co & 15);
-    float s = 0.f;
-    for (int c = 0; c < nwg; ++c) s += src[(size_t)c * 256];
-    dW[i] = s;
+    for (int c = j; c < nwg; c += 8) s += src[(size_t)c * 256];
+  }
+  red[j][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (j == 0 && i < total) {
+    float v = red[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v += red[q][threadIdx.x];
+    dW[i] = v;
   }
 }
 
@@ -438,12 +459,20 @@ __global__ __launch_bounds__(256) void k_conv0_wgrad(const int *__restrict__ n_o
   for (int i = threadIdx.x; i < 125 * 8; i += blockDim.x)
     part[(size_t)blockIdx.x * 1000 + i] = (acc_s[0][i] + acc_s[1][i]) + (acc_s[2][i] + acc_s[3][i]);
 }
-__global__ void k_conv0_wgrad_reduce(const float *__restrict__ part, int nwg, float *__restrict__ dW /* [125][1][8] */) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 1000) return;
+__global__ __launch_bounds__(256) void k_conv0_wgrad_reduce(const float *__restrict__ part, int nwg, float *__restrict__ dW /* [125][1][8] */) {
+  __shared__ float red[8][32];
+  const int j = threadIdx.x >> 5, i = blockIdx.x * 32 + (threadIdx.x & 31);
   float s = 0.f;
-  for (int w = 0; w < nwg; ++w) s += part[(size_t)w * 1000 + i];
-  dW[i] = s;
+  if (i < 1000)
+    for (int w = j; w < nwg; w += 8) s += part[(size_t)w * 1000 + i];
+  red[j][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (j == 0 && i < 1000) {
+    float v = red[0][threadIdx.x];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) v += red[q][threadIdx.x];
+    dW[i] = v;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
