@@ -118,8 +118,14 @@ def check(rc: int) -> None:
         raise SpsError(rc, lib.sps_last_error().decode())
 
 
+_LAYOUTS: dict = {}
+
+
 def weight_layout(out_channels: int = 1):
-    """[(name, offset, numel)] of the weight blob, from the library itself."""
+    """((name, offset, numel), ...) of the weight blob, from the library itself (asked once per head width)."""
+    cached = _LAYOUTS.get(out_channels)
+    if cached is not None:
+        return cached
     out = []
     buf = C.create_string_buffer(128)
     off, num = C.c_int64(), C.c_int64()
@@ -129,7 +135,8 @@ def weight_layout(out_channels: int = 1):
     for i in range(n):
         check(lib.sps_head_tensor_info(out_channels, i, buf, 128, C.byref(off), C.byref(num)))
         out.append((buf.value.decode(), off.value, num.value))
-    return out
+    _LAYOUTS[out_channels] = tuple(out)
+    return _LAYOUTS[out_channels]
 
 
 class Weights:

@@ -499,7 +499,7 @@ int sps_train_backward(sps_ctx *c, const float *dscores, const float *scores, fl
     int rc = SPS_OK;
     if (op.kind == T_CONV0) {
       hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
-      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(32), dim3(256), 0, st, t->c0part, C0_WG, t->grad + cs.w_off);
+      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(125), dim3(256), 0, st, t->c0part, C0_WG, t->grad + cs.w_off);
       continue;  // the input feature is a constant: no data gradient
     }
     // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated

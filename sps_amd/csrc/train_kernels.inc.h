@@ -459,18 +459,18 @@ __global__ __launch_bounds__(256) void k_conv0_wgrad(const int *__restrict__ n_o
   for (int i = threadIdx.x; i < 125 * 8; i += blockDim.x)
     part[(size_t)blockIdx.x * 1000 + i] = (acc_s[0][i] + acc_s[1][i]) + (acc_s[2][i] + acc_s[3][i]);
 }
+// 8 outputs per workgroup; 32 threads per output add every 32nd workgroup partial (ascending), then meet in LDS in order
 __global__ __launch_bounds__(256) void k_conv0_wgrad_reduce(const float *__restrict__ part, int nwg, float *__restrict__ dW /* [125][1][8] */) {
-  __shared__ float red[8][32];
-  const int j = threadIdx.x >> 5, i = blockIdx.x * 32 + (threadIdx.x & 31);
+  __shared__ float red[32][8];
+  const int j = threadIdx.x >> 3, i = blockIdx.x * 8 + (threadIdx.x & 7);  // 125 workgroups x 8 = the 1000 outputs
   float s = 0.f;
-  if (i < 1000)
-    for (int w = j; w < nwg; w += 8) s += part[(size_t)w * 1000 + i];
-  red[j][threadIdx.x & 31] = s;
+  for (int w = j; w < nwg; w += 32) s += part[(size_t)w * 1000 + i];
+  red[j][threadIdx.x & 7] = s;
   __syncthreads();
-  if (j == 0 && i < 1000) {
+  if (j == 0) {
     float v = red[0][threadIdx.x];
 #pragma unroll
-    for (int q = 1; q < 8; ++q) v += red[q][threadIdx.x];
+    for (int q = 1; q < 32; ++q) v += red[q][threadIdx.x];
     dW[i] = v;
   }
 }

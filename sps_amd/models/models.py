@@ -69,6 +69,7 @@ class NativeBackboneModule(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         self._dev_weights = {}
         self._blob = None
+        self._plan = None                # .to() / .cuda() replace the buffer tensors: the training plan is rebuilt
         return super()._apply(fn, *args, **kwargs)
 
     def device_weights(self, device_index: int) -> "_native.Weights":
@@ -127,29 +128,25 @@ class _TrainForward(torch.autograd.Function):
     @staticmethod
     def forward(fctx, module, coordinates, *params):
         dev = coordinates.device
-        oc = module.MinkUNet.out_channels
-        layout = _native.weight_layout(oc)
-        sd = module.MinkUNet.state_dict(keep_vars=True)
         with torch.cuda.device(dev):
             stream = torch.cuda.current_stream().cuda_stream
             ctx = get_context(dev.index or 0, stream)
-            blob = module._flat_state(dev)          # parameters + BN buffers: views of one tensor in the native layout
+            plan = module._train_plan(dev)          # parameters + BN buffers: views of one tensor in the native layout
+            blob = plan.flat
             n = coordinates.shape[0]
             scores = torch.empty(n, dtype=torch.float32, device=dev)
-            n_stats = 3 * sum(int(sd[name].shape[-1]) for name, _, _ in layout if name.endswith(".kernel"))
-            stats = torch.zeros(n_stats, dtype=torch.float32, device=dev)
+            stats = torch.zeros(plan.n_stats, dtype=torch.float32, device=dev)
             ctx.train_forward(blob.data_ptr(), blob.numel(), coordinates.data_ptr(), coordinates.stride(0), n,
                               module.voxel_size, scores.data_ptr(), stats.data_ptr(), stream)
         fctx.save_for_backward(scores)
-        fctx.native = (ctx, layout, [(id(p), tuple(p.shape)) for p in params], {name: id(sd[name]) for name, _, _ in layout},
-                       blob.numel())
+        fctx.native = (ctx, [plan.span_of[id(p)] + (tuple(p.shape),) for p in params], blob.numel())
         fctx.mark_non_differentiable(stats)
         return scores, stats
 
     @staticmethod
     def backward(fctx, dscores, _dstats):
         (scores,) = fctx.saved_tensors
-        ctx, layout, param_ids, name_ids, numel = fctx.native
+        ctx, spans, numel = fctx.native
         with torch.cuda.device(scores.device):
             stream = torch.cuda.current_stream().cuda_stream
             grad = torch.empty(numel, dtype=torch.float32, device=scores.device)
@@ -162,12 +159,14 @@ class _TrainForward(torch.autograd.Function):
             if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and _TrainForward.sync_gradients:
                 dist.all_reduce(grad, op=dist.ReduceOp.SUM)
                 grad.div_(dist.get_world_size())
-        by_id = {name_ids[name]: (off, num) for name, off, num in layout}
-        out = []
-        for (pid, shape), need in zip(param_ids, fctx.needs_input_grad[2:]):
-            off, num = by_id[pid]
-            out.append(grad[off: off + num].view(shape) if need else None)
+        out = [grad[off: off + num].view(shape) if need else None
+               for (off, num, shape), need in zip(spans, fctx.needs_input_grad[2:])]
         return (None, None, *out)
+
+
+class _TrainPlan:
+    """What a training step needs from the module, computed once per placement of the module's tensors."""
+    __slots__ = ("flat", "checks", "params", "span_of", "n_stats", "run_idx", "stat_idx", "nbt")
 
 
 class SPSModel(NativeBackboneModule):
@@ -200,56 +199,69 @@ class SPSModel(NativeBackboneModule):
     def _train_forward(self, coordinates: torch.Tensor) -> torch.Tensor:
         if coordinates.shape[0] == 0:
             raise ValueError("a training step needs at least one point")
-        params = [p for p in self.MinkUNet.parameters()]
-        scores, stats = _TrainForward.apply(self, coordinates, *params)
-        self._update_running_stats(coordinates.device, stats)
+        plan = self._train_plan(coordinates.device)
+        scores, stats = _TrainForward.apply(self, coordinates, *plan.params)
+        self._update_running_stats(plan, stats)
         self.mark_weights_dirty()          # the optimiser is about to change the parameters: eval contexts re-upload
         return scores
 
     @torch.no_grad()
-    def _flat_state(self, device) -> torch.Tensor:
+    def _train_plan(self, device) -> _TrainPlan:
         """Every parameter and BatchNorm buffer of the backbone as a VIEW of one flat float32 device tensor in the native
         blob layout (sps_weights_tensor_info): the training step hands the library one pointer instead of concatenating
-        194 tensors, and the optimiser's in-place updates keep it current.  Rebuilt when the storage moved (.cuda(), .to())."""
+        194 tensors, and the optimiser's in-place updates keep it current.  Rebuilt when the storage moved (.cuda(), .to(),
+        a parameter's .data re-assigned): every step checks the 194 addresses, nothing else is recomputed."""
+        plan = getattr(self, "_plan", None)
+        if plan is not None and plan.flat.device == device:
+            base = plan.flat.data_ptr()
+            if all(t.data_ptr() == base + byte_off for t, byte_off in plan.checks):
+                return plan
         layout = _native.weight_layout(self.MinkUNet.out_channels)
         sd = self.MinkUNet.state_dict(keep_vars=True)
-        flat = getattr(self, "_flat", None)
-        ok = flat is not None and flat.device == device and all(
-            sd[name].data_ptr() == flat.data_ptr() + 4 * off and sd[name].dtype == torch.float32 for name, off, _ in layout)
-        if not ok:
-            flat = torch.cat([sd[name].detach().reshape(-1).to(device=device, dtype=torch.float32) for name, _, _ in layout])
-            for name, off, num in layout:
-                t = sd[name]
-                t.data = flat[off: off + num].view(t.shape)
-            self._flat = flat
-        return flat
-
-    @torch.no_grad()
-    def _update_running_stats(self, device, stats: torch.Tensor) -> None:
-        """nn.BatchNorm1d bookkeeping in train mode: running = (1 - m) running + m batch (m = 0.1; the library delivers
-        the batch mean and the UNBIASED batch variance), num_batches_tracked += 1 -- three multi-tensor kernels, no sync."""
-        sd = self.MinkUNet.state_dict(keep_vars=True)
-        rm, rv, nbt, bm, bv = [], [], [], [], []
-        off = 0
-        for name, _, _ in _native.weight_layout(self.MinkUNet.out_channels):
+        flat = torch.cat([sd[name].detach().reshape(-1).to(device=device, dtype=torch.float32) for name, _, _ in layout])
+        for name, off, num in layout:
+            t = sd[name]
+            t.data = flat[off: off + num].view(t.shape)
+        plan = _TrainPlan()
+        plan.flat = flat
+        plan.checks = [(sd[name], 4 * off) for name, off, _ in layout]
+        plan.params = list(self.MinkUNet.parameters())
+        plan.span_of = {id(sd[name]): (off, num) for name, off, num in layout}
+        # BatchNorm running statistics: their positions in the flat tensor / of their batch values in the `stats` vector the
+        # library returns (per conv in layout order: mean, biased var, unbiased var, C values each)
+        span = {name: (off, num) for name, off, num in layout}
+        run, stat, nbt, soff = [], [], [], 0
+        for name, _, _ in layout:
             if not name.endswith(".kernel"):
                 continue
             conv = name[: -len(".kernel")]
             c = int(sd[name].shape[-1])
             if conv != "final":
                 bn = _bn_of_conv(conv)
-                rm.append(sd[bn + ".bn.running_mean"])
-                rv.append(sd[bn + ".bn.running_var"])
+                for which, col in ((".bn.running_mean", 0), (".bn.running_var", 2)):
+                    off, num = span[bn + which]
+                    assert num == c
+                    run.append(torch.arange(off, off + c))
+                    stat.append(torch.arange(soff + col * c, soff + (col + 1) * c))
                 nbt.append(sd[bn + ".bn.num_batches_tracked"])
-                bm.append(stats[off: off + c])
-                bv.append(stats[off + 2 * c: off + 3 * c])
-            off += 3 * c
+            soff += 3 * c
+        plan.n_stats = soff
+        plan.run_idx = torch.cat(run).to(device)
+        plan.stat_idx = torch.cat(stat).to(device)
+        plan.nbt = nbt
+        self._plan = plan
+        return plan
+
+    @torch.no_grad()
+    def _update_running_stats(self, plan: _TrainPlan, stats: torch.Tensor) -> None:
+        """nn.BatchNorm1d bookkeeping in train mode: running = (1 - m) running + m batch (m = 0.1; the library delivers
+        the batch mean and the UNBIASED batch variance), num_batches_tracked += 1 -- six small kernels on index vectors
+        that were built once, no synchronisation."""
         m = 0.1
-        torch._foreach_mul_(rm, 1 - m)
-        torch._foreach_add_(rm, bm, alpha=m)
-        torch._foreach_mul_(rv, 1 - m)
-        torch._foreach_add_(rv, bv, alpha=m)
-        torch._foreach_add_(nbt, 1)
+        cur = plan.flat.index_select(0, plan.run_idx)
+        cur.mul_(1 - m).add_(stats.index_select(0, plan.stat_idx), alpha=m)
+        plan.flat.index_copy_(0, plan.run_idx, cur)
+        torch._foreach_add_(plan.nbt, 1)
 
 
 class SPSNet(nn.Module):
@@ -280,19 +292,26 @@ class SPSNet(nn.Module):
 
     # ---- training (models.py:62-82, :154-160) -------------------------------------------------------------------
     @staticmethod
-    def r2score(preds: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
-        """torchmetrics.R2Score: 1 - sum (y - p)^2 / sum (y - mean y)^2."""
-        ss_res = torch.sum((target - preds) ** 2)
-        ss_tot = torch.sum((target - target.mean()) ** 2)
+    def r2score(preds: torch.Tensor, target: torch.Tensor, weight: torch.Tensor = None, count=None) -> torch.Tensor:
+        """torchmetrics.R2Score: 1 - sum (y - p)^2 / sum (y - mean y)^2 (over the points of weight 1 when weights are given)."""
+        if weight is None:
+            weight = torch.ones_like(target)
+            count = target.numel()
+        ss_res = torch.sum(weight * (target - preds) ** 2)
+        mean = torch.sum(weight * target) / count
+        ss_tot = torch.sum(weight * (target - mean) ** 2)
         return 1.0 - ss_res / ss_tot
 
     def common_step(self, batch: torch.Tensor):
         coordinates = batch[:, :5].reshape(-1, 5)
         gt_labels = batch[:, 5].reshape(-1)
-        scan_indices = torch.nonzero(coordinates[:, 4] == 1).reshape(-1)        # np.where(t == 1) on the host in the reference
         scores = self.model(coordinates)
-        loss = self.loss(scores[scan_indices], gt_labels[scan_indices])
-        r2 = self.r2score(scores[scan_indices].detach(), gt_labels[scan_indices])
+        # the reference selects the scan's points (t == 1) with np.where on the host (models.py:65-68): here the same
+        # means are written with a 0/1 weight so that the step never waits for the GPU (no index list, no size to learn)
+        w = (coordinates[:, 4] == 1).to(scores.dtype)
+        cnt = w.sum()
+        loss = (w * (scores - gt_labels) ** 2).sum() / cnt            # nn.MSELoss over the selected points
+        r2 = self.r2score(scores.detach(), gt_labels, w, cnt)
         return loss, r2
 
     def training_step(self, batch: torch.Tensor, batch_idx: int, dataloader_idx: int = 0):
@@ -304,8 +323,11 @@ class SPSNet(nn.Module):
         return {"val_loss": loss, "val_r2": r2}
 
     def configure_optimizers(self):
-        optimizer = torch.optim.Adam(self.parameters(), lr=self.hparams["TRAIN"]["LR"],
-                                     weight_decay=self.hparams["TRAIN"]["WEIGHT_DECAY"])
+        params = list(self.parameters())
+        # same Adam as the reference (models.py:154-160); on the GPU the single-launch ("fused") implementation of it
+        fused = bool(params) and all(p.is_cuda for p in params) and os.environ.get("SPS_FUSED_ADAM", "1") != "0"
+        optimizer = torch.optim.Adam(params, lr=self.hparams["TRAIN"]["LR"],
+                                     weight_decay=self.hparams["TRAIN"]["WEIGHT_DECAY"], fused=fused)
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=self.hparams["TRAIN"]["LR_EPOCH"],
                                                     gamma=self.hparams["TRAIN"]["LR_DECAY"])
         return [optimizer], [scheduler]

@@ -22,7 +22,7 @@ def test_c_and_numpy_oracles_agree():
 
 def test_blob_layouts_agree():
     from sps_amd import _native        # loading the library needs no GPU
-    assert c_oracle.layout() == _native.weight_layout()
+    assert list(c_oracle.layout()) == list(_native.weight_layout())
     names = {n for n, _, _ in c_oracle.layout()}
     assert set(O.random_params(0).keys()) == names
 

@@ -29,6 +29,7 @@ torch.cuda.synchronize()
 t = time.perf_counter()
 for _ in range(args.steps):
     loss = step()
+host = (time.perf_counter() - t) / args.steps          # time to ISSUE a step (the loop never waits for the GPU)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t) / args.steps
 # forward only / backward only
@@ -37,4 +38,4 @@ opt.zero_grad(set_to_none=True)
 e[0].record(); out = net.training_step(batch, 0); e[1].record(); out["loss"].backward(); e[2].record()
 torch.cuda.synchronize()
 print(f"rows {len(batch)}: {dt * 1e3:.2f} ms per training step ({1 / dt:.1f} steps/s), loss {float(loss.detach()):.4f}; "
-      f"GPU forward {e[0].elapsed_time(e[1]):.2f} ms, backward {e[1].elapsed_time(e[2]):.2f} ms")
+      f"GPU forward {e[0].elapsed_time(e[1]):.2f} ms, backward {e[1].elapsed_time(e[2]):.2f} ms; host issue {host * 1e3:.2f} ms per step")
