@@ -1,7 +1,8 @@
 #!/bin/bash
 # Evidence set of one build, collected on the GPU box into gpurun_out/<tag>/ (copy what is to be judged into profiles/<tag>/):
 #   bench lines (default, driver protocol, serial, configs 3 and 4), rocprofv3 kernel stats (serial and pipelined),
-#   HBM traffic from separate FETCH_SIZE / WRITE_SIZE passes, SQ / TA / TCP counters per conv layer.
+#   HBM traffic from separate FETCH_SIZE / WRITE_SIZE passes, SQ / TA / TCP counters per conv layer, training-step and
+#   online-filter timings.
 # usage: gpurun -- bash tools/collect_evidence.sh <tag>
 tag=${1:-round2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -25,8 +26,12 @@ rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VMEM_RD
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $o/pmc_b -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
 python3 tools/pmc_table.py $o/pmc_a $o/pmc_b > $o/pmc_conv_layers.txt 2>> $o/bench.err
 python3 tools/pmc_derive.py $o/pmc_conv_layers.txt > $o/pmc_conv_layers_derived.txt 2>> $o/bench.err
-rm -rf $o/prof_serial $o/prof_pipelined $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/pmc_a $o/pmc_b
-ls -la $o; tail -3 $o/bench.err; cat $o/traffic_summary.txt; cat $o/pmc_conv_layers_derived.txt | head -30
+python3 tools/train_timing.py --steps 50 2>> $o/bench.err | tail -1 > $o/train_timing.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_train -- python3 tools/train_timing.py --steps 20 > /dev/null 2>> $o/bench.err
+cp $(ls $o/prof_train/*/*kernel_stats.csv | head -1) $o/kernel_stats_train.csv
+python3 tools/filter_timing.py 2>> $o/bench.err | tail -4 > $o/filter_timing.txt
+rm -rf $o/prof_train $o/prof_serial $o/prof_pipelined $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/pmc_a $o/pmc_b
+ls -la $o; tail -3 $o/bench.err; cat $o/train_timing.txt $o/filter_timing.txt; cat $o/traffic_summary.txt; cat $o/pmc_conv_layers_derived.txt | head -30
 python3 -c "
 import json
 for f in ('bench','bench_driver_protocol','bench_serial_1stream','bench_config3','bench_config4'):
