@@ -384,8 +384,34 @@ class SPSNet(nn.Module):
         self.recall.append(m["recall"])
         self.F1.append(m["f1"])
         if self.save_vis:
-            raise NotImplementedError("save_vis (.npy dumps, models.py:113-152) is out of scope")
+            save_vis(os.path.join(self.data_dir, "predictions", self.test_seq[0]), batch, batch_idx, scores)
         return m
+
+
+def save_vis(root: str, batch: torch.Tensor, batch_idx: int, scores: torch.Tensor) -> list:
+    """The .npy dumps of models.py:113-152: per batch index b, ``<root>/scans/<batch_idx>_<b>.npy`` = scan rows
+    (x, y, z, label, score) and ``<root>/maps/<batch_idx>_<b>.npy`` = submap rows (x, y, z, label).  As in the
+    reference the score column is the POOLED scan scores of the whole batch tensor, so a batch of more than one scan
+    trips the same length assertion (prediction runs with BATCH_SIZE 1, predict.py:50).  Returns the written paths."""
+    s_path, m_path = os.path.join(root, "scans"), os.path.join(root, "maps")
+    os.makedirs(s_path, exist_ok=True)
+    os.makedirs(m_path, exist_ok=True)
+    rows = batch.detach().cpu().numpy()
+    sc = scores.detach().cpu().numpy().reshape(-1)
+    is_scan = rows[:, -2] == 1
+    pooled = sc[is_scan]
+    written = []
+    for b in np.unique(rows[:, 0]):
+        of_b = rows[:, 0] == b
+        scan, submap = rows[of_b & is_scan], rows[of_b & ~is_scan & (rows[:, -2] == 0)]
+        assert len(scan) == len(pooled), "Lengths of arrays are not equal."
+        b_name = str(b.item())                                                 # a float column: '0.0', as torch's .item()
+        scan_pth = os.path.join(s_path, f"{batch_idx}_{b_name}.npy")
+        map_pth = os.path.join(m_path, f"{batch_idx}_{b_name}.npy")
+        np.save(scan_pth, np.column_stack((scan[:, 1:4], scan[:, -1], pooled)))
+        np.save(map_pth, np.column_stack((submap[:, 1:4], submap[:, -1])))
+        written += [scan_pth, map_pth]
+    return written
 
 
 def metrics_from_sums(s) -> dict:

@@ -260,3 +260,25 @@ def test_augmentation_matches_reference_goldens():
     # no augmentation outside the training split
     ds = blt.BacchusDataset(cfg, [d["scan0"]], d["pc_map"])
     np.testing.assert_array_equal(ds[0].numpy(), d["item0"])
+
+
+def test_save_vis_dumps(tmp_path):
+    """models.py:113-152: file names, column layout, the pooled-score length assertion for batches of more than one scan."""
+    import torch
+    from sps_amd.models.models import save_vis
+    rng = np.random.default_rng(5)
+    scan = np.column_stack([np.zeros(7), rng.normal(size=(7, 3)), np.ones(7), rng.random(7)])
+    submap = np.column_stack([np.zeros(5), rng.normal(size=(5, 3)), np.zeros(5), rng.random(5)])
+    batch = torch.from_numpy(np.vstack([scan, submap]).astype(np.float32))
+    scores = torch.from_numpy(rng.random(12).astype(np.float32))
+    paths = save_vis(str(tmp_path / "predictions" / "seq"), batch, 3, scores)
+    assert [p.split("predictions")[1] for p in paths] == ["/seq/scans/3_0.0.npy", "/seq/maps/3_0.0.npy"]
+    s, m = np.load(paths[0]), np.load(paths[1])
+    assert s.shape == (7, 5) and m.shape == (5, 4)
+    np.testing.assert_array_equal(s[:, :3], batch[:7, 1:4].numpy())
+    np.testing.assert_array_equal(s[:, 3], batch[:7, 5].numpy())
+    np.testing.assert_array_equal(s[:, 4], scores[:7].numpy())
+    np.testing.assert_array_equal(m, np.column_stack([batch[7:, 1:4].numpy(), batch[7:, 5].numpy()]))
+    two = torch.cat([batch, torch.cat([torch.ones(12, 1), batch[:, 1:]], dim=1)])
+    with pytest.raises(AssertionError):
+        save_vis(str(tmp_path / "p2"), two, 0, torch.cat([scores, scores]))
