@@ -10,13 +10,15 @@ from sps_amd.models.models import SPSNet
 ap = argparse.ArgumentParser()
 ap.add_argument("--azimuth", type=int, default=1750)
 ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--batch", type=int, default=1, help="scans per training step (the reference's config.yaml trains with BATCH_SIZE 2)")
 args = ap.parse_args()
 cfg = dict(bench.CFG)
 cfg["TRAIN"] = {"LR": 7e-5, "WEIGHT_DECAY": 1e-4, "LR_EPOCH": 1, "LR_DECAY": 0.99}
 torch.manual_seed(0)
 net = bench.synthetic_weights(SPSNet(cfg)).cuda().train()
 (opt,), _ = net.configure_optimizers()
-batch = torch.from_numpy(synthetic.make_scene(scan_seed=1, n_azimuth=args.azimuth)["batch"]).cuda()
+batch = torch.from_numpy(synthetic.collate([synthetic.make_scene(scan_seed=1 + b, x_offset=3.0 * b, n_azimuth=args.azimuth)["batch"]
+                                            for b in range(args.batch)])).cuda()
 def step():
     opt.zero_grad(set_to_none=True)
     out = net.training_step(batch, 0)
