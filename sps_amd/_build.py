@@ -36,14 +36,25 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """Compile sps_amd/csrc/*.hip -> libsps_hip.so (gfx950 only).  Returns the library path."""
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-o", LIB + ".tmp"] + SOURCES
-    if verbose:
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    import fcntl
+    # several ranks of one job may arrive here together (torchrun): one builds, the others wait and find it fresh
+    with open(LIB + ".lock", "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not is_stale():
+                return LIB
+            tmp = f"{LIB}.{os.getpid()}.tmp"
+            cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", tmp] + SOURCES
+            if verbose:
+                print(" ".join(cmd))
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+                raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+            os.replace(tmp, LIB)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB
 
 
