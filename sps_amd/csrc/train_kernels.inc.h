@@ -87,8 +87,7 @@ __device__ inline void bn_block_reduce(BnAcc &s, int C, double (*red)[16][BN_MAX
   }
 }
 // k_bn_finish / k_bn_bwd_finish (one workgroup; a "last workgroup done" ticket inside the statistics kernel was measured:
-// the device-scope fence it needs writes back the XCD's L2 -- 70 us per launch with a fence in every thread, 16 us with
-// ONE fence per workgroup, against 5.3 + 5.2 us for the two launches): sum the BN_WG partials of channel c
+// the device-scope fence it needs writes back the XCD's L2 and cost 70 us per launch): sum the BN_WG partials of channel c
 // in index order.  1024 / C threads per channel take contiguous runs of partials, the runs meet in LDS in run order.
 // Returns the two sums in (t0, t1) for threads < C.
 __device__ inline void bn_combine(const double *__restrict__ vp, int C, double (*red)[16][BN_MAXC], double &t0, double &t1) {
