@@ -58,9 +58,13 @@ class NativeBackboneModule(nn.Module):
         self._dev_weights = {}           # device index -> _native.Weights holding this module's current parameters
         self._blob = None                # host copy of the weight blob in the native layout
         # any load_state_dict that reaches the backbone (predict.py:58 or util.py:39) re-uploads
-        self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self.mark_weights_dirty())
+        self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self._on_load_state_dict())
 
     # ---- weights -> native blob ---------------------------------------------------------
+    def _on_load_state_dict(self) -> None:
+        self.mark_weights_dirty()
+        self._plan = None                # load_state_dict(assign=True) replaces the tensors: the training plan is rebuilt
+
     def mark_weights_dirty(self) -> None:
         """Call after modifying parameters in place; load_state_dict / .cuda() / .to() do it themselves."""
         self._dev_weights = {}

@@ -74,7 +74,7 @@ def test_training_is_deterministic_and_reduces_the_loss():
     params = O.random_params(seed=2)
     _, o1, g1 = native_step(params, batch)
     _, o2, g2 = native_step(params, batch)
-    assert float(o1["loss"]) == float(o2["loss"])
+    assert float(o1["loss"].detach()) == float(o2["loss"].detach())
     for k in g1:
         np.testing.assert_array_equal(g1[k], g2[k], err_msg=k)            # fixed-order reductions: same bits every run
     cfg = dict(CFG)
@@ -169,3 +169,32 @@ def test_training_after_the_context_was_compact():
     for k in g0:
         np.testing.assert_array_equal(g0[k], g1[k], err_msg=k)
     c.set_level_fractions(None)
+
+
+@pytest.mark.timeout(600)
+def test_training_follows_replaced_and_moved_tensors():
+    """The cached training plan (flat views of the parameters) must notice load_state_dict(assign=True) and .to():
+    after either, a step computes exactly what a freshly built model with the same weights computes."""
+    batch = synthetic.small_scene(seed=9, n_scan=600)
+    dev = torch.from_numpy(batch).cuda()
+    net = net_from_params(O.random_params(seed=2)).cuda().train()
+    net.training_step(dev, 0)["loss"].backward()                     # builds the plan
+    other = net_from_params(O.random_params(seed=4)).cuda().train()
+    sd = {k: v.detach().clone() for k, v in other.state_dict().items()}
+    net.load_state_dict(sd, assign=True)
+    net.zero_grad(set_to_none=True)
+    out = net.training_step(dev, 0)
+    out["loss"].backward()
+    want = other.training_step(dev, 0)
+    want["loss"].backward()
+    torch.cuda.synchronize()
+    assert float(out["loss"].detach()) == float(want["loss"].detach())
+    for (k, p), (_, q) in zip(net.named_parameters(), other.named_parameters()):
+        assert torch.equal(p.grad, q.grad), k
+    # a round trip through the host re-creates every tensor
+    net = net.cpu().cuda()
+    net.zero_grad(set_to_none=True)
+    again = net.training_step(dev, 0)
+    torch.cuda.synchronize()
+    # the first step updated the BatchNorm running statistics only: the train-mode forward does not read them
+    assert float(again["loss"].detach()) == float(out["loss"].detach())
