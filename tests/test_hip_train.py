@@ -198,3 +198,33 @@ def test_training_follows_replaced_and_moved_tensors():
     torch.cuda.synchronize()
     # the first step updated the BatchNorm running statistics only: the train-mode forward does not read them
     assert float(again["loss"].detach()) == float(out["loss"].detach())
+
+
+@pytest.mark.timeout(600)
+def test_training_step_with_the_reference_batch_of_two_scans():
+    """config.yaml trains with BATCH_SIZE 2: two collated scans (batch indices 0 and 1, overlapping coordinates) in one
+    step -- loss, train-mode scores and every gradient against the autograd oracle."""
+    a = synthetic.small_scene(seed=21, n_scan=500)
+    b = synthetic.small_scene(seed=22, n_scan=650)
+    batch = synthetic.collate([a, b])
+    assert set(np.unique(batch[:, 0])) == {0.0, 1.0}
+    params = O.random_params(seed=5)
+    loss_ref, scores_ref, grads_ref, _ = T.train_step(params, batch, VS)
+    net, out, grads = native_step(params, batch)
+    assert float(out["loss"].detach()) == pytest.approx(loss_ref, rel=2e-5)
+    bad = {}
+    for name, want in grads_ref.items():
+        got = grads[name].reshape(want.shape)
+        assert np.isfinite(got).all(), name
+        e = rel_err(got, want)
+        if e > 2e-3:
+            bad[name] = e
+    assert not bad, f"gradient mismatch (relative to the tensor's max): {bad}"
+    # the two scans do not see each other (they only share the BatchNorm statistics): a batch made of the same scan twice
+    # gives both copies the same scores, up to the rounding of differently grouped MFMA sums (the copies' rows fall into
+    # different 16-row tiles, whose lists of present offsets group the products differently)
+    twice = synthetic.collate([a, a])
+    net.zero_grad(set_to_none=True)
+    with torch.enable_grad():
+        s = net(torch.from_numpy(twice).cuda()).detach().cpu().numpy()
+    np.testing.assert_allclose(s[: len(a)], s[len(a):], rtol=0, atol=2e-6)
