@@ -92,6 +92,23 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_W4
 #define SPS_W4 4
 #endif
+// pair-exact conv (k_conv_px): waves per supertile, chunks in flight, offsets staged per batch, min waves / SIMD --
+// level 0 (thousands of supertiles: every workgroup resident at once) and the coarser levels (few supertiles: short chains)
+#ifndef SPS_PX0
+#define SPS_PX0 4, 1, 8, true
+#endif
+#ifndef SPS_PX0_W
+#define SPS_PX0_W 7
+#endif
+#ifndef SPS_PX1
+#define SPS_PX1 4, 2, 8, true
+#endif
+#ifndef SPS_PX1_W
+#define SPS_PX1_W 4
+#endif
+#ifndef SPS_PX_DEFAULT
+#define SPS_PX_DEFAULT 3
+#endif
 #include "keys_hash.inc.h"
 #include "grid_kernels.inc.h"
 #include "map_kernels.inc.h"
@@ -498,6 +515,11 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   return g;
 }
 
+template <int NW, int G, int KB, bool PIPE, int CIN, bool C8, bool DS, bool FIN, int MINW>
+void launch_px(dim3 grid, hipStream_t st, const ConvArgs &a) {
+  hipLaunchKernelGGL((k_conv_px<NW, G, KB, PIPE, CIN, C8, DS, FIN, MINW>), grid, dim3(NW * 64), 0, st, a);
+}
+
 // k_conv instantiation for a launch geometry (column tiles per wave x splits) -- shared by inference and training
 int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t st) {
 #define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
@@ -622,6 +644,36 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     }
   }
   const bool ds = cs.ds_cin > 0;
+  // one-column-tile layers over a 3x3x3x3 map: pair-exact kernel (k_conv_px).  SPS_PX = bit mask of the levels that use it
+  // (DIAGNOSTICS: A/B against k_conv; read once)
+  static const int px_levels = [] { const char *e = getenv("SPS_PX"); return e ? atoi(e) : SPS_PX_DEFAULT; }();
+  if (((px_levels >> cc.level_out) & 1) && cs.K == 81 && a.NT == 1 && a.nbr && a.tmask && (cs.cout == 8 || cs.cout == 16) &&
+      (cs.cin == 8 || cs.cin == 16 || cs.cin == 24) && (!cc.fin || cs.cout == 8)) {
+    int64_t gs = (c->cap / 64) >> cc.level_out;  // expected supertiles at this level
+    if (gs < 64) gs = 64;
+    if (gs > 4096) gs = 4096;
+    const dim3 gridp((unsigned)gs);
+    const int key = cs.cin * 100 + (cs.cout == 8 ? 10 : 0) + (cc.fin ? 2 : (ds ? 1 : 0));
+#define SPS_PX_LAUNCH(CIN_, C8_, DS_, FIN_)                                                                                   \
+  do {                                                                                                                        \
+    if (cc.level_out == 0)                                                                                                    \
+      launch_px<SPS_PX0, CIN_, C8_, DS_, FIN_, (C8_ || SPS_PX0_W < 5) ? SPS_PX0_W : 5>(gridp, st, a);                                                   \
+    else                                                                                                                      \
+      launch_px<SPS_PX1, CIN_, C8_, DS_, FIN_, (C8_ || SPS_PX1_W < 5) ? SPS_PX1_W : 5>(gridp, st, a);                                                   \
+  } while (0)
+    switch (key) {
+      case 800: SPS_PX_LAUNCH(8, false, false, false); break;   // block2.conv1
+      case 810: SPS_PX_LAUNCH(8, true, false, false); break;    // block1.conv1 / conv2
+      case 811: SPS_PX_LAUNCH(8, true, true, false); break;     // block8.conv2 (heads: `final` not fused)
+      case 812: SPS_PX_LAUNCH(8, true, true, true); break;      // block8.conv2 + `final`
+      case 1601: SPS_PX_LAUNCH(16, false, true, false); break;  // block2.conv2, block7.conv2
+      case 1610: SPS_PX_LAUNCH(16, true, false, false); break;  // block8.conv1
+      case 2400: SPS_PX_LAUNCH(24, false, false, false); break; // block7.conv1
+      default: return fail(SPS_ERR_INVALID, "no k_conv_px instantiation for %s", cc.name);
+    }
+#undef SPS_PX_LAUNCH
+    return SPS_OK;
+  }
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
   if (cc.fin) {
     hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
@@ -1602,6 +1654,12 @@ int sps_get_logits(sps_ctx *c, float *logits_dev) {
 int sps_debug_wave_trace(unsigned long long *host, int n_waves) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wave_trace), (size_t)n_waves * 4 * sizeof(unsigned long long)));
+  return SPS_OK;
+}
+// k_conv_px: 8 stamps (shader clock) per wave of the first 4096 supertiles of the traced layer
+int sps_debug_px_trace(unsigned long long *host, int n_waves) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_px_trace), (size_t)n_waves * 8 * sizeof(unsigned long long)));
   return SPS_OK;
 }
 #endif
