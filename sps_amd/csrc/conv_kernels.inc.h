@@ -36,6 +36,12 @@ struct ConvArgs {
   const float *fin_w;
   float *fin_out;
   float fin_b;
+  // rulebook of the level's 3x3x3x3 map (k_conv_px; built by k_maps): per supertile of 64 rows and time slice the chunk
+  // count, the offset of every chunk and 16 (input row << 6 | output row) entries per chunk
+  const uint32_t *rb_e;
+  const unsigned char *rb_k;
+  const int *rb_cnt;  // [supertiles][4]
+  int rb_supertiles;  // supertiles the rulebook arrays hold
 };
 
 // Output-stationary sparse convolution on f32 MFMA.
@@ -371,20 +377,22 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 // Pair-exact sparse convolution for the one-column-tile layers (C_out <= 16) over a 3x3x3x3 map.
 //   k_conv executes every present offset of a 16-row tile for all 16 rows although only 43-57 % of those
 //   (row, offset) slots hold a neighbour (17.4 pairs per row against 40.4 present offsets per tile at level 0):
-//   2.3x of its gathers and MFMAs multiply zeros.  Here a workgroup owns a SUPERTILE of 64 output rows; wave w
-//   takes the present offsets j = w, w + 4, ... of the supertile's list, compacts the (output row, input row)
-//   PAIRS of each offset with a ballot (the rulebook of that offset, built on the fly from the neighbour table),
-//   and runs them in chunks of 16 pairs: one gather of 16 input rows, the offset's weight fragment, the MFMAs in
-//   the TRANSPOSED orientation D^T[co][pair] = W[k]^T . In^T -- so a lane ends up with four consecutive output
+//   2.3x of its gathers and MFMAs multiply zeros.  The pair-exact path works on the RULEBOOK of the map instead:
+//   k_maps (build_nbr3) compacts, for every SUPERTILE of 64 output rows and every present offset, the
+//   (output row, input row) PAIRS with the ballot it takes anyway and stores them offset after offset (k ascending) in
+//   chunks of 16 pairs (padded per offset); k_conv_px then runs a supertile per workgroup: its chunks are dealt
+//   round-robin to the waves; one chunk = one gather of 16 input rows, the offset's weight fragment and the MFMAs
+//   in the TRANSPOSED orientation D^T[co][pair] = W[k]^T . In^T -- so a lane ends up with four consecutive output
 //   channels of ONE pair, which it adds to the pair's row of the wave's private 64-row accumulator in LDS with one
-//   16-byte read and one 16-byte write (a row occurs at most once per offset and the LDS operations of a wave
-//   execute in order: no atomics).  The four private accumulators are summed in wave order by the epilogue:
-//   bit-reproducible.  Slots executed: 1.31 per pair (chunks are padded per offset) instead of 2.3.
-//   C_in = 8 layers (and the last 8 channels of C_in = 24) use 8-byte gathers and two MFMAs per chunk (lane group
-//   q = channels 2q, 2q + 1).
-//   List entry: (input row << 6) | output row inside the supertile; PAD entries gather zeros (OOR) into a dummy row.
-constexpr uint32_t PX_PAD = 0xFFFFFFFFu;
+//   16-byte read and one 16-byte write (a row occurs at most once per chunk and the LDS operations of a wave
+//   execute in order: no atomics).  The private accumulators are summed in wave order by the epilogue:
+//   bit-reproducible.  Slots executed: 1.31 per pair instead of 2.3.  C_in = 8 layers (and the last 8 channels of
+//   C_in = 24) use 8-byte gathers and two MFMAs per chunk (lane group q = channels 2q, 2q + 1).
+//   Rulebook entry: (input row << 6) | output row inside the supertile; PAD entries gather zeros (OOR) into a
+//   dummy accumulator row.  Per supertile: three segments (time slices), each with its chunk count, the offset of every
+//   chunk (1 byte) and 16 entries per chunk (map_kernels.inc.h).
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
 #if defined(SPS_WAVE_TRACE)
 __device__ unsigned long long g_px_trace[8 * 16384];
 #define PX_STAMP(i) if (tr_on) tr[i] = __builtin_amdgcn_s_memtime()
@@ -392,26 +400,24 @@ __device__ unsigned long long g_px_trace[8 * 16384];
 #define PX_STAMP(i)
 #endif
 template <int G>
-struct ChunkRegs {
+struct PxEntries {  // rulebook words of a group of G chunks
+  uint32_t ev[G], kv[G];
+};
+template <int G>
+struct PxOperands {  // gathered rows + weight fragments of a group of G chunks
   u32x4 va[G], vb[G];
   u32x2 xa[G], xb[G];
   uint32_t e[G];
 };
-template <int NW, int G, int KB, bool PIPE, int CIN, bool C8, bool DS, bool FIN, int MINW>
+template <int NW, int G, int NS, int CIN, bool C8, bool DS, bool FIN, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   constexpr int AST = C8 ? 12 : 20;    // floats per accumulator row: 16-byte aligned, strides 48 / 80 B spread the banks
   constexpr int ACCN = 64 * AST + 16;  // + one dummy row (PAD slots)
-  constexpr int CAPC = KB * 4;         // chunks of one staging batch (an offset has at most 64 pairs = 4 chunks)
   constexpr bool W128 = CIN >= 16, W64 = CIN != 16;  // 16-byte part (channels 0..15), 8-byte part (8 channels)
   constexpr uint32_t OFF64 = CIN == 24 ? 64u : 0u;   // byte offset of the 8-byte part inside a row
   constexpr uint32_t U64 = CIN == 24 ? 4u : 0u;      // first weight unit of the 8-byte part
-  static_assert(KB == 4 || KB == 8 || KB == 12 || KB == 16, "KB: whole 4-byte words of the offset list");
   static_assert(NW == 4 || NW == 8, "waves per supertile");
-  constexpr int KLW = 128 / NW;        // bytes of the offset list per wave (81 offsets / NW <= 21 / 11)
   __shared__ __attribute__((aligned(16))) float acc_s[NW][ACCN];
-  __shared__ uint32_t list_s[NW][CAPC * 16];
-  __shared__ uint32_t cw_s[NW][CAPC];
-  __shared__ __attribute__((aligned(16))) unsigned char klist[NW][128 + 16];
 #if defined(SPS_WAVE_TRACE)
   unsigned long long tr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool tr_on = a.trace_on;
@@ -419,21 +425,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   PX_STAMP(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  // the first supertile's mask words do not depend on the row count: fetch them alongside it and the abort flag
-  // (saves a dependent round trip; tile_cap = tiles the mask buffer was allocated for)
-  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void *)a.tmask, 0, a.tile_cap * 16, 0x00020000);
-  const u32x4 tw_first = __builtin_amdgcn_raw_buffer_load_b128(rsM, (uint32_t)((int)blockIdx.x * 4 + q) * 16u, 0, 0);
+  // the first supertile's chunk counts do not depend on the row count: fetch them alongside (one round trip less)
+  int4 nseg_first = make_int4(0, 0, 0, 0);
+  if ((int)blockIdx.x < a.rb_supertiles) nseg_first = *reinterpret_cast<const int4 *>(a.rb_cnt + (size_t)blockIdx.x * 4);
   const int aborted = a.abort_flag ? *a.abort_flag : 0;
   const int count = *a.n_out;
   if (aborted) return;
   const int nst = (count + 63) >> 6;
-  const int ntiles = (count + 15) >> 4;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsA2 =
       __builtin_amdgcn_make_buffer_rsrc((void *)(DS ? a.in2 : a.in), 0, (int)(DS ? a.in2_bytes : a.in_bytes), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
-  const uint32_t ldn32 = (uint32_t)a.ldn;
   const uint32_t ldi4 = (uint32_t)a.ldi * 4u;
   // weight fragment offsets inside an offset's block: unit q / channels 2q, 2q+1 of the 8-byte part, column n.  C_out <= 8: the
   // columns 8..15 are zero padding -- their lanes ask for an out-of-range address (zeros, no cache access)
@@ -443,35 +445,18 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   const uint32_t wk64 = ((uint32_t)n * 16u + (U64 + (uint32_t)(q >> 1)) * 256u + (uint32_t)(q & 1) * 8u) | wpad;
   const uint32_t ga128 = (uint32_t)q * 16u, ga64 = OFF64 + (uint32_t)q * 8u;
   const uint32_t kwbytes = (uint32_t)a.upk * 256u;  // weights of one offset
-  unsigned char *kl = klist[wave];
-  uint32_t *li = list_s[wave];
-  uint32_t *cw = cw_s[wave];
   float *acc = acc_s[wave];
-  const unsigned long long lt = (1ull << lane) - 1ull;
   const bool rmw = !C8 || q < 2;  // C_out <= 8: lane groups 2, 3 hold the zero-padded channels 8..15
 
   for (int st = blockIdx.x; st < nst; st += gridDim.x) {
     const int row0 = st * 64;
-    const int row = row0 + lane;
-    const bool rv = row < count;
-    // ---- present offsets of the supertile: OR of its four tile masks (tiles past the end count as zero).  The offset
-    // of rank r goes to slot (r % NW) * KLW + r / NW: wave w finds ITS offsets (r = w, w + NW, ...) in one run
-    u32x4 tw = st == (int)blockIdx.x ? tw_first : __builtin_amdgcn_raw_buffer_load_b128(rsM, (uint32_t)(st * 4 + q) * 16u, 0, 0);
-    if (st * 4 + q >= ntiles) tw = u32x4{0u, 0u, 0u, 0u};
-    uint32_t un0 = tw.x, un1 = tw.y, un2 = tw.z;
-    un0 |= __shfl_xor(un0, 16, 64), un1 |= __shfl_xor(un1, 16, 64), un2 |= __shfl_xor(un2, 16, 64);
-    un0 |= __shfl_xor(un0, 32, 64), un1 |= __shfl_xor(un1, 32, 64), un2 |= __shfl_xor(un2, 32, 64);
-    int nk;
-    {
-      const uint32_t w0 = lane < 32 ? un0 : un1;
-      const bool b0 = (w0 >> (lane & 31)) & 1u, b1 = lane < 32 && ((un2 >> lane) & 1u);
-      const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
-      const int n0 = __popcll(bal0);
-      const int r0 = __popcll(bal0 & lt), r1 = n0 + __popcll(bal1 & lt);
-      if (b0) kl[(r0 % NW) * KLW + r0 / NW] = (unsigned char)((lane >> 5) * 27 + (lane & 31));
-      if (b1) kl[(r1 % NW) * KLW + r1 / NW] = (unsigned char)(54 + lane);
-      nk = n0 + __popcll(bal1);
-    }
+    const int4 nseg = st == (int)blockIdx.x ? nseg_first : *reinterpret_cast<const int4 *>(a.rb_cnt + (size_t)st * 4);
+    const int n0 = nseg.x, n01 = nseg.x + nseg.y;
+    const int nch = n01 + nseg.z;  // chunk c lives in segment 0 (c < n0), 1 (c < n01) or 2
+    const __amdgpu_buffer_rsrc_t rsE =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.rb_e + (size_t)st * (PX_CH_MAX * 16)), 0, PX_CH_MAX * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsK =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(a.rb_k + (size_t)st * PX_KSTRIDE), 0, PX_KSTRIDE, 0x00020000);
     // ---- zero this wave's accumulator (rows 0..63 + dummy)
     for (int i = lane; i < ACCN / 4; i += 64) reinterpret_cast<floatx4 *>(acc)[i] = floatx4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_wave_barrier();
@@ -495,124 +480,107 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       }
       if (rmw) *reinterpret_cast<floatx4 *>(acc + (16 * wave + n) * AST + 4 * q) = d;  // the row is still zero
     }
+    PX_STAMP(2);
+    PX_STAMP(3);
 
-    // ---- this wave's offsets, KB at a time: neighbour rows -> ballot -> chunk-padded pair lists -> chunks
-    const int nmine = nk > wave ? (nk - wave + NW - 1) / NW : 0;
-    for (int jb = 0; jb < nmine; jb += KB) {
-      uint32_t kq[KB / 4];
+    // ---- chunks wave, wave + NW, ...: groups of G, software pipeline -- rulebook words and operand loads of the next groups
+    // are in flight while the MFMAs and accumulator updates of group i run.  Everything past the end of the list is an
+    // out-of-range load (zeros) / a PAD slot.
+    const int ngrp = nch > wave ? ((nch - wave + NW - 1) / NW + G - 1) / G : 0;
+    auto fetch = [&](PxEntries<G> &x, int i) {
 #pragma unroll
-      for (int i = 0; i < KB / 4; ++i)
-        kq[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)*reinterpret_cast<const uint32_t *>(kl + wave * KLW + jb + 4 * i));
-      int idx[KB];
-#pragma unroll
-      for (int b = 0; b < KB; ++b) {
-        const int k = (int)((kq[b >> 2] >> (8 * (b & 3))) & 0xFFu);  // wave-uniform
-        const uint32_t w = k < 27 ? tw.x : (k < 54 ? tw.y : tw.z);  // this lane's own tile: entries of absent (tile, k) are never written
-        const int bit = k < 27 ? k : (k < 54 ? k - 27 : k - 54);
-        const bool has = jb + b < nmine && rv && ((w >> bit) & 1u);
-        const uint32_t off = has ? ((uint32_t)k * ldn32 + (uint32_t)row) * 4u : OOR;
-        const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
-        idx[b] = has ? v : -1;
+      for (int g = 0; g < G; ++g) {
+        const int c = wave + NW * (i * G + g);                                // wave-uniform
+        const int seg = c < n0 ? 0 : (c < n01 ? 1 : 2);
+        const int lc = c - (c < n0 ? 0 : (c < n01 ? n0 : n01));               // chunk inside its segment
+        const bool on = c < nch;
+        x.ev[g] = __builtin_amdgcn_raw_buffer_load_b32(rsE, on ? (uint32_t)((seg * PX_SEG_CH + lc) * 16 + n) * 4u : OOR, 0, 0);
+        x.kv[g] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsK, on ? (uint32_t)(seg * 112 + lc) : OOR, 0, 0);
       }
-      if (jb == 0) PX_STAMP(2);
-      int nch = 0;
+    };
+    auto issue = [&](PxOperands<G> &r, const PxEntries<G> &x, int i) {
 #pragma unroll
-      for (int b = 0; b < KB; ++b) {
-        const uint32_t k = (kq[b >> 2] >> (8 * (b & 3))) & 0xFFu;
-        const bool pr = idx[b] >= 0;
-        const unsigned long long bal = __ballot(pr);
-        const int cnt = __popcll(bal);
-        if (pr) li[nch * 16 + __popcll(bal & lt)] = ((uint32_t)idx[b] << 6) | (uint32_t)lane;
-        if (lane < ((-cnt) & 15)) li[nch * 16 + cnt + lane] = PX_PAD;
-        const int nc = (cnt + 15) >> 4;
-        if (lane < nc) cw[nch + lane] = k * kwbytes;
-        nch += nc;
-      }
-      __builtin_amdgcn_wave_barrier();
-      if (jb == 0) PX_STAMP(3);
-      // ---- chunks: G per group, software-pipelined -- the loads of the next group are in flight while the MFMAs and the
-      // accumulator updates of the current one run (two register sets; a group past the end loads nothing: PAD / OOR)
-      auto issue = [&](ChunkRegs<G> &r, int c0) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int c = c0 + g;
-          const int cc = min(c, nch - 1);
-          const uint32_t ev = li[cc * 16 + n];
-          r.e[g] = c < nch ? ev : PX_PAD;
+      for (int g = 0; g < G; ++g) {
+        const int c = wave + NW * (i * G + g);
+        r.e[g] = c < nch ? x.ev[g] : PX_PAD;
 #if defined(PX_ABLATE_B)
-          const uint32_t wk = 0x80000000u;
+        const uint32_t wk = 0x80000000u;
 #else
-          const uint32_t wk = c < nch ? cw[cc] : 0x80000000u;
+        const uint32_t wk = c < nch ? x.kv[g] * kwbytes : 0x80000000u;
 #endif
 #if defined(PX_ABLATE_A)
-          const uint32_t ioff = OOR;
+        const uint32_t ioff = OOR;
 #else
-          const uint32_t ioff = r.e[g] == PX_PAD ? OOR : (r.e[g] >> 6) * ldi4;
+        const uint32_t ioff = r.e[g] == PX_PAD ? OOR : (r.e[g] >> 6) * ldi4;
 #endif
-          if (W128) {
-            r.va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
-            r.vb[g] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wk + wk128, 0, 0);
-          }
-          if (W64) {
-            r.xa[g] = __builtin_amdgcn_raw_buffer_load_b64(rsA, ioff + ga64, 0, 0);
-            r.xb[g] = __builtin_amdgcn_raw_buffer_load_b64(rsW, wk + wk64, 0, 0);
-          }
+        if (W128) {
+          r.va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
+          r.vb[g] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wk + wk128, 0, 0);
         }
-      };
-      auto compute = [&](const ChunkRegs<G> &r) {
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          const int orow = r.e[g] == PX_PAD ? 64 : (int)(r.e[g] & 63u);
-          floatx4 *ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
-          floatx4 cur = floatx4{0.f, 0.f, 0.f, 0.f};
-#if !defined(PX_ABLATE_RMW)
-          if (rmw) cur = *ap;
-#endif
-          floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
-#if defined(PX_ABLATE_MFMA)
-          if (W128) d = floatx4{__uint_as_float(r.vb[g].x ^ r.va[g].x), __uint_as_float(r.vb[g].y ^ r.va[g].y), __uint_as_float(r.vb[g].z ^ r.va[g].z), __uint_as_float(r.vb[g].w ^ r.va[g].w)};
-          if (W64) d.x += __uint_as_float(r.xb[g].x ^ r.xa[g].x), d.y += __uint_as_float(r.xb[g].y ^ r.xa[g].y);
-#else
-          if (W128) {
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].x), __uint_as_float(r.va[g].x), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].y), __uint_as_float(r.va[g].y), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].z), __uint_as_float(r.va[g].z), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].w), __uint_as_float(r.va[g].w), d, 0, 0, 0);
-          }
-          if (W64) {
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[g].x), __uint_as_float(r.xa[g].x), d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[g].y), __uint_as_float(r.xa[g].y), d, 0, 0, 0);
-          }
-#endif
-#if defined(PX_ABLATE_RMW)
-          if (rmw && r.e[g] == 0x12345u) *ap = cur + d;
-#else
-          if (rmw) *ap = cur + d;
-#endif
-        }
-      };
-      if (PIPE) {
-        ChunkRegs<G> r0, r1;
-        if (nch > 0) issue(r0, 0);
-        for (int c0 = 0; c0 < nch; c0 += 2 * G) {
-          issue(r1, c0 + G);
-          compute(r0);
-          issue(r0, c0 + 2 * G);
-          if (c0 + G < nch) compute(r1);
-        }
-      } else {
-        for (int c0 = 0; c0 < nch; c0 += G) {
-          ChunkRegs<G> r0;
-          issue(r0, c0);
-          compute(r0);
+        if (W64) {
+          r.xa[g] = __builtin_amdgcn_raw_buffer_load_b64(rsA, ioff + ga64, 0, 0);
+          r.xb[g] = __builtin_amdgcn_raw_buffer_load_b64(rsW, wk + wk64, 0, 0);
         }
       }
-      __builtin_amdgcn_wave_barrier();
+    };
+    auto compute = [&](const PxOperands<G> &r) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const int orow = r.e[g] == PX_PAD ? 64 : (int)(r.e[g] & 63u);
+        floatx4 *ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
+        floatx4 cur = floatx4{0.f, 0.f, 0.f, 0.f};
+#if !defined(PX_ABLATE_RMW)
+        if (rmw) cur = *ap;
+#endif
+        floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
+#if defined(PX_ABLATE_MFMA)
+        if (W128) d = floatx4{__uint_as_float(r.vb[g].x ^ r.va[g].x), __uint_as_float(r.vb[g].y ^ r.va[g].y), __uint_as_float(r.vb[g].z ^ r.va[g].z), __uint_as_float(r.vb[g].w ^ r.va[g].w)};
+        if (W64) d.x += __uint_as_float(r.xb[g].x ^ r.xa[g].x), d.y += __uint_as_float(r.xb[g].y ^ r.xa[g].y);
+#else
+        if (W128) {
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].x), __uint_as_float(r.va[g].x), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].y), __uint_as_float(r.va[g].y), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].z), __uint_as_float(r.va[g].z), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].w), __uint_as_float(r.va[g].w), d, 0, 0, 0);
+        }
+        if (W64) {
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[g].x), __uint_as_float(r.xa[g].x), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[g].y), __uint_as_float(r.xa[g].y), d, 0, 0, 0);
+        }
+#endif
+#if defined(PX_ABLATE_RMW)
+        if (rmw && r.e[g] == 0x12345u) *ap = cur + d;
+#else
+        if (rmw) *ap = cur + d;
+#endif
+      }
+    };
+    if (ngrp > 0) {
+      // ring of NS operand sets: the loads of NS - 1 groups are in flight while one group computes; the rulebook words run
+      // another NS groups ahead.  Set j holds group i + j of the iteration; set (j + NS - 1) % NS is refilled before it.
+      PxEntries<G> x[NS];
+      PxOperands<G> r[NS];
+#pragma unroll
+      for (int j = 0; j < NS; ++j) fetch(x[j], j);
+#pragma unroll
+      for (int j = 0; j < NS - 1; ++j) {
+        issue(r[j], x[j], j);
+        fetch(x[j], j + NS);
+      }
+      for (int i = 0; i < ngrp; i += NS) {
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+          const int s2 = (j + NS - 1) % NS;
+          issue(r[s2], x[s2], i + j + NS - 1);
+          fetch(x[s2], i + j + 2 * NS - 1);
+          if (i + j < ngrp) compute(r[j]);
+        }
+      }
     }
     PX_STAMP(4);
     __syncthreads();
     PX_STAMP(5);
-    // ---- epilogue: the four partial sums in wave order, BN scale / shift, residual, ReLU, store (+ `final`)
+    // ---- epilogue: the partial sums in wave order, BN scale / shift, residual, ReLU, store (+ `final`)
     {
       constexpr int TPR = NW;                    // threads per row: NW * 64 threads, 64 rows
       constexpr int CPT = (C8 ? 8 : 16) / TPR;   // columns per thread
@@ -644,7 +612,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
     PX_STAMP(6);
 #if defined(SPS_WAVE_TRACE)
     if (tr_on && lane == 0 && st < 4096) {
-      tr[7] = ((unsigned long long)nk << 32) | (unsigned)st;
+      tr[7] = ((unsigned long long)nch << 32) | (unsigned)st;
       if (wave < 4) for (int i = 0; i < 8; ++i) g_px_trace[(st * 4 + wave) * 8 + i] = tr[i];
     }
 #endif

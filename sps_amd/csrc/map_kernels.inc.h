@@ -39,7 +39,19 @@ struct MapsArgs {
   const int *counts;
   int chunk_off[NLV + 1];
   int64_t ldn[NLV];  // row stride of the level's tables (= its row capacity)
+  // rulebook of the 3x3x3x3 map (levels whose layers run pair-exact, else null; layout: conv_kernels.inc.h, k_conv_px)
+  uint32_t *rb_e[NLV];
+  unsigned char *rb_k[NLV];
+  int *rb_cnt[NLV];
 };
+
+// Rulebook layout per SUPERTILE of 64 output rows: three segments (one per time slice dt = -1, 0, +1) of up to PX_SEG_CH
+// chunks; a chunk = 16 entries (input row << 6 | output row inside the supertile) of ONE offset, padded with PX_PAD.
+constexpr uint32_t PX_PAD = 0xFFFFFFFFu;
+constexpr int PX_SEG_CH = 108;   // chunks of a segment: 27 offsets x (64 rows / 16)
+constexpr int PX_CH_MAX = 324;   // chunks of a supertile
+constexpr int PX_KSTRIDE = 336;  // bytes of the chunk -> offset table of a supertile (3 x 112)
+constexpr int PX_LEVELS = 3;     // levels that may run pair-exact (0..2)
 
 __device__ inline int level_of_chunk(const MapsArgs &a, int first_level, int &local, int bid) {
   int l = first_level;
@@ -98,6 +110,12 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   const int64_t ldn = a.ldn[l];
   const int lane = threadIdx.x & 63;
   const int nround = (n + 63) & ~63;  // whole waves take part in the ballots
+  // rulebook (pair-exact layers): a wave = the 64 rows of one supertile; the pairs of each of the slice's 27 offsets are
+  // compacted with the offset's ballot and appended, chunk-padded, to the supertile's segment of this slice
+  uint32_t *__restrict__ rbe = a.rb_e[l];
+  unsigned char *__restrict__ rbk = a.rb_k[l];
+  int *__restrict__ rbc = a.rb_cnt[l];
+  const unsigned long long ltm = (1ull << lane) - 1ull;
   for (int u = local * 256 + (int)threadIdx.x; u < nround; u += nchunks * 256) {
     const bool ok = u < n;
     const int r = ok ? L.vblock[u] : 0;
@@ -107,6 +125,9 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
     // the run x = px-1 .. px+1 touches the block at offset 0 and at most one of the blocks at -1 / +1
     const int side = px == 0 ? -1 : (px == 3 ? 1 : 0);
     uint32_t m = 0u;
+    int cb = 0;  // chunks written to the segment so far
+    uint32_t *__restrict__ eb = rbe ? rbe + ((size_t)(u >> 6) * PX_CH_MAX + (size_t)slice * PX_SEG_CH) * 16 : nullptr;
+    unsigned char *__restrict__ kb = rbk ? rbk + (size_t)(u >> 6) * PX_KSTRIDE + slice * 112 : nullptr;
 #pragma unroll 3
     for (int c = 0; c < 9; ++c) {
       const int dy = c % 3 - 1, dz = c / 3 - 1;
@@ -134,9 +155,18 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
         // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
         if (any && ok) nbr[(size_t)(27 * slice + j) * ldn + u] = row;
         m |= any ? 1u << j : 0u;
+        if (eb) {  // wave-uniform
+          const int cnt = __popcll(bal);
+          if (row >= 0) eb[cb * 16 + __popcll(bal & ltm)] = ((uint32_t)row << 6) | (uint32_t)lane;
+          if (lane < ((-cnt) & 15)) eb[cb * 16 + cnt + lane] = PX_PAD;
+          const int nc = (cnt + 15) >> 4;
+          if (lane < nc) kb[cb + lane] = (unsigned char)(27 * slice + j);
+          cb += nc;
+        }
       }
     }
     if ((lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = m;
+    if (eb && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = cb;
   }
 }
 

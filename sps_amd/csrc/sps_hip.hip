@@ -92,16 +92,16 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_W4
 #define SPS_W4 4
 #endif
-// pair-exact conv (k_conv_px): waves per supertile, chunks in flight, offsets staged per batch, min waves / SIMD --
-// level 0 (thousands of supertiles: every workgroup resident at once) and the coarser levels (few supertiles: short chains)
+// pair-exact conv (k_conv_px): waves per supertile, chunks per pipeline group, operand sets of the pipeline -- level 0 (thousands of supertiles: every
+// workgroup resident at once) and the coarser levels (few supertiles: short chains); min waves / SIMD; default level mask
 #ifndef SPS_PX0
-#define SPS_PX0 4, 1, 8, true
+#define SPS_PX0 4, 1, 2
 #endif
 #ifndef SPS_PX0_W
 #define SPS_PX0_W 7
 #endif
 #ifndef SPS_PX1
-#define SPS_PX1 4, 2, 8, true
+#define SPS_PX1 8, 1, 2
 #endif
 #ifndef SPS_PX1_W
 #define SPS_PX1_W 4
@@ -147,6 +147,10 @@ struct Level {
   int *nbr3 = nullptr;         // [81][cap]
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
   uint32_t *tm3 = nullptr, *tmdown = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
+  // rulebook of the 3x3x3x3 map (levels that run k_conv_px): per supertile of 64 rows
+  uint32_t *rb_e = nullptr;       // [cap/64][PX_CH_MAX][16] pair entries
+  unsigned char *rb_k = nullptr;  // [cap/64][PX_KSTRIDE] offset of each chunk
+  int *rb_cnt = nullptr;          // [cap/64][4] chunks per time slice
   LevelView view() const { return LevelView{vblock, vbit, bkey, bmask, bbase, badj, bparent, bchild}; }
 };
 
@@ -254,6 +258,13 @@ struct sps_ctx {
 
 namespace {
 
+// levels whose one-column-tile 3x3x3x3 layers run pair-exact (k_rulebook + k_conv_px).  SPS_PX = bit mask (DIAGNOSTICS:
+// A/B against k_conv; read once)
+int px_levels() {
+  static const int m = [] { const char *e = getenv("SPS_PX"); return (e ? atoi(e) : SPS_PX_DEFAULT) & ((1 << PX_LEVELS) - 1); }();
+  return m;
+}
+
 int dev_alloc(sps_ctx *c, void **p, size_t bytes) {
   hipError_t e = hipMalloc(p, bytes ? bytes : 16);
   if (e != hipSuccess) return fail(SPS_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -337,6 +348,12 @@ int reserve(sps_ctx *c, int64_t n) {
       if (l == 0) ALLOC(L.sbit, unsigned char, cap);
       ALLOC(L.inv, int, l == 0 ? cap : c->capl[l - 1]);     // point -> row (level 0); fine row -> parent row (levels >= 1)
       ALLOC(L.nbr3, int, 81 * rows);
+      L.rb_e = nullptr, L.rb_k = nullptr, L.rb_cnt = nullptr;
+      if (l < PX_LEVELS && ((px_levels() >> l) & 1)) {  // capacities are multiples of 1024
+        ALLOC(L.rb_e, uint32_t, (rows / 64) * (int64_t)(PX_CH_MAX * 16));
+        ALLOC(L.rb_k, unsigned char, (rows / 64) * (int64_t)PX_KSTRIDE);
+        ALLOC(L.rb_cnt, int, (rows / 64) * 4);
+      }
       if (l > 0) {
         ALLOC(L.down, int, 8 * rows);
       }
@@ -515,9 +532,9 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   return g;
 }
 
-template <int NW, int G, int KB, bool PIPE, int CIN, bool C8, bool DS, bool FIN, int MINW>
+template <int NW, int G, int NS, int CIN, bool C8, bool DS, bool FIN, int MINW>
 void launch_px(dim3 grid, hipStream_t st, const ConvArgs &a) {
-  hipLaunchKernelGGL((k_conv_px<NW, G, KB, PIPE, CIN, C8, DS, FIN, MINW>), grid, dim3(NW * 64), 0, st, a);
+  hipLaunchKernelGGL((k_conv_px<NW, G, NS, CIN, C8, DS, FIN, MINW>), grid, dim3(NW * 64), 0, st, a);
 }
 
 // k_conv instantiation for a launch geometry (column tiles per wave x splits) -- shared by inference and training
@@ -644,22 +661,24 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     }
   }
   const bool ds = cs.ds_cin > 0;
-  // one-column-tile layers over a 3x3x3x3 map: pair-exact kernel (k_conv_px).  SPS_PX = bit mask of the levels that use it
-  // (DIAGNOSTICS: A/B against k_conv; read once)
-  static const int px_levels = [] { const char *e = getenv("SPS_PX"); return e ? atoi(e) : SPS_PX_DEFAULT; }();
-  if (((px_levels >> cc.level_out) & 1) && cs.K == 81 && a.NT == 1 && a.nbr && a.tmask && (cs.cout == 8 || cs.cout == 16) &&
+  // one-column-tile layers over a 3x3x3x3 map: pair-exact kernel over the level's rulebook (k_conv_px)
+  if (cc.level_out < PX_LEVELS && ((px_levels() >> cc.level_out) & 1) && c->lv[cc.level_out].rb_e && cs.K == 81 && a.NT == 1 && a.nbr && a.tmask && (cs.cout == 8 || cs.cout == 16) &&
       (cs.cin == 8 || cs.cin == 16 || cs.cin == 24) && (!cc.fin || cs.cout == 8)) {
     int64_t gs = (c->cap / 64) >> cc.level_out;  // expected supertiles at this level
     if (gs < 64) gs = 64;
     if (gs > 4096) gs = 4096;
     const dim3 gridp((unsigned)gs);
+    a.rb_e = c->lv[cc.level_out].rb_e;
+    a.rb_k = c->lv[cc.level_out].rb_k;
+    a.rb_cnt = c->lv[cc.level_out].rb_cnt;
+    a.rb_supertiles = (int)(c->capl[cc.level_out] / 64);
     const int key = cs.cin * 100 + (cs.cout == 8 ? 10 : 0) + (cc.fin ? 2 : (ds ? 1 : 0));
-#define SPS_PX_LAUNCH(CIN_, C8_, DS_, FIN_)                                                                                   \
-  do {                                                                                                                        \
-    if (cc.level_out == 0)                                                                                                    \
-      launch_px<SPS_PX0, CIN_, C8_, DS_, FIN_, (C8_ || SPS_PX0_W < 5) ? SPS_PX0_W : 5>(gridp, st, a);                                                   \
-    else                                                                                                                      \
-      launch_px<SPS_PX1, CIN_, C8_, DS_, FIN_, (C8_ || SPS_PX1_W < 5) ? SPS_PX1_W : 5>(gridp, st, a);                                                   \
+#define SPS_PX_LAUNCH(CIN_, C8_, DS_, FIN_)                                                                  \
+  do {                                                                                                       \
+    if (cc.level_out == 0)                                                                                   \
+      launch_px<SPS_PX0, CIN_, C8_, DS_, FIN_, SPS_PX0_W>(gridp, st, a);                                     \
+    else                                                                                                     \
+      launch_px<SPS_PX1, CIN_, C8_, DS_, FIN_, SPS_PX1_W>(gridp, st, a);                                     \
   } while (0)
     switch (key) {
       case 800: SPS_PX_LAUNCH(8, false, false, false); break;   // block2.conv1
@@ -1117,6 +1136,9 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   }
   ma.chunk_off[NLV] = off;
   ma.counts = c->counts;
+  // rulebooks of the levels whose layers run pair-exact (inference only: the training convs use k_conv)
+  for (int l = 0; l < PX_LEVELS; ++l)
+    if (((px_levels() >> l) & 1) && !fo.front_only) ma.rb_e[l] = c->lv[l].rb_e, ma.rb_k[l] = c->lv[l].rb_k, ma.rb_cnt[l] = c->lv[l].rb_cnt;
   for (int l = 0; l < NLV; ++l) ma.ldn[l] = c->capl[l];
   // (the 5x5x5x1 map is never materialised: conv0 is fused with it, k_conv0_fused)
   if (no_merge & 4) {

@@ -1,6 +1,6 @@
 """Phase timeline of the pair-exact conv kernel (DIAGNOSTIC): private -DSPS_WAVE_TRACE build (loaded through $SPS_LIB, the
-product library is never touched); k_conv_px stamps the shader clock at wave entry, after the offset list, after the
-neighbour loads, after the first pair lists, after the chunk loops, after the workgroup barrier and after the epilogue.
+product library is never touched); k_conv_px stamps the shader clock at wave entry, after the counts, after the
+fused downsample branch, after the chunk loop, after the workgroup barrier and after the epilogue.
   gpurun -- python tools/px_trace.py --layer block8.0.conv1 [--flags "-DSPS_PX_G=4"]"""
 import argparse, ctypes as C, os, shutil, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,10 +37,10 @@ try:
     t0 = t[:, 0].min()
     us = lambda x: x / args.mhz
     pct = lambda x: " ".join(f"{np.percentile(x, p):7.2f}" for p in (0, 10, 50, 90, 99, 100))
-    print(f"layer {args.layer}: {len(t)} waves, span {us(t[:, 6].max() - t0):.2f} us, offsets per supertile {pct(nk)}")
+    print(f"layer {args.layer}: {len(t)} waves, span {us(t[:, 6].max() - t0):.2f} us, chunks per supertile {pct(nk)}")
     print("entry (since first wave)            [us] p0 p10 p50 p90 p99 p100:", pct(us(t[:, 0] - t0)))
-    names = ["count + masks + offset list + zero", "DS + neighbour loads issued", "pair lists of the first batch",
-             "chunk loops (all batches)", "wait at the barrier", "epilogue"]
+    names = ["count + chunk count + zero", "fused downsample branch", "-",
+             "chunk loop", "wait at the barrier", "epilogue"]
     for i, nm in enumerate(names):
         print(f"{nm:36s}[us]", pct(us(t[:, i + 1] - t[:, i])))
     print(f"{'lifetime':36s}[us]", pct(us(t[:, 6] - t[:, 0])))
