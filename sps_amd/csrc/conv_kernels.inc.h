@@ -381,7 +381,7 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
 //   k_maps (build_nbr3) compacts, for every SUPERTILE of 64 output rows and every present offset, the
 //   (output row, input row) PAIRS with the ballot it takes anyway and stores them offset after offset (k ascending) in
 //   chunks of 16 pairs (padded per offset); k_conv_px then runs a supertile per workgroup: its chunks are dealt
-//   round-robin to the waves; one chunk = one gather of 16 input rows, the offset's weight fragment and the MFMAs
+//   to the waves in blocks of four; one chunk = one gather of 16 input rows, the offset's weight fragment and the MFMAs
 //   in the TRANSPOSED orientation D^T[co][pair] = W[k]^T . In^T -- so a lane ends up with four consecutive output
 //   channels of ONE pair, which it adds to the pair's row of the wave's private 64-row accumulator in LDS with one
 //   16-byte read and one 16-byte write (a row occurs at most once per chunk and the LDS operations of a wave
@@ -400,22 +400,19 @@ __device__ unsigned long long g_px_trace[8 * 16384];
 #define PX_STAMP(i)
 #endif
 template <int G>
-struct PxEntries {  // rulebook words of a group of G chunks
-  uint32_t ev[G], kv[G];
-};
-template <int G>
 struct PxOperands {  // gathered rows + weight fragments of a group of G chunks
   u32x4 va[G], vb[G];
   u32x2 xa[G], xb[G];
   uint32_t e[G];
 };
-template <int NW, int G, int NS, int CIN, bool C8, bool DS, bool FIN, int MINW>
+template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW>
 __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   constexpr int AST = C8 ? 12 : 20;    // floats per accumulator row: 16-byte aligned, strides 48 / 80 B spread the banks
   constexpr int ACCN = 64 * AST + 16;  // + one dummy row (PAD slots)
   constexpr bool W128 = CIN >= 16, W64 = CIN != 16;  // 16-byte part (channels 0..15), 8-byte part (8 channels)
   constexpr uint32_t OFF64 = CIN == 24 ? 64u : 0u;   // byte offset of the 8-byte part inside a row
   constexpr uint32_t U64 = CIN == 24 ? 4u : 0u;      // first weight unit of the 8-byte part
+  constexpr bool QUAD = CIN == 24;                   // quad-contiguous gather of the 16-byte part (see issue())
   static_assert(NW == 4 || NW == 8, "waves per supertile");
   __shared__ __attribute__((aligned(16))) float acc_s[NW][ACCN];
 #if defined(SPS_WAVE_TRACE)
@@ -483,98 +480,113 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
     PX_STAMP(2);
     PX_STAMP(3);
 
-    // ---- chunks wave, wave + NW, ...: groups of G, software pipeline -- rulebook words and operand loads of the next groups
-    // are in flight while the MFMAs and accumulator updates of group i run.  Everything past the end of the list is an
-    // out-of-range load (zeros) / a PAD slot.
-    const int ngrp = nch > wave ? ((nch - wave + NW - 1) / NW + G - 1) / G : 0;
-    auto fetch = [&](PxEntries<G> &x, int i) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int c = wave + NW * (i * G + g);                                // wave-uniform
-        const int seg = c < n0 ? 0 : (c < n01 ? 1 : 2);
-        const int lc = c - (c < n0 ? 0 : (c < n01 ? n0 : n01));               // chunk inside its segment
-        const bool on = c < nch;
-        x.ev[g] = __builtin_amdgcn_raw_buffer_load_b32(rsE, on ? (uint32_t)((seg * PX_SEG_CH + lc) * 16 + n) * 4u : OOR, 0, 0);
-        x.kv[g] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsK, on ? (uint32_t)(seg * 112 + lc) : OOR, 0, 0);
-      }
+    // ---- chunks in BLOCKS of four consecutive chunks; block b goes to wave b % NW.  One 4-byte load per lane fetches the
+    // rulebook words of a whole block (lane group j = chunk j of the block) and one byte load per chunk its offset; the words
+    // of chunk j reach all lane groups through ds_bpermute.  Software pipeline: the words of the next block and the operand
+    // loads of the next chunk are in flight while the MFMAs and the accumulator update of the current chunk run.
+    // Everything past the end of the list is an out-of-range load (zeros) / a PAD slot.
+    const int nblk = (nch + 3) >> 2;
+    const int nbw = nblk > wave ? (nblk - wave + NW - 1) / NW : 0;  // blocks of this wave
+    auto fetch = [&](uint32_t &ev, uint32_t &kv, int t) {
+      const int c = 4 * (wave + NW * t) + q;  // this lane group's chunk
+      const int seg = c < n0 ? 0 : (c < n01 ? 1 : 2);
+      const int lc = c - (c < n0 ? 0 : (c < n01 ? n0 : n01));  // chunk inside its segment
+      const bool on = t < nbw && c < nch;
+      ev = __builtin_amdgcn_raw_buffer_load_b32(rsE, on ? (uint32_t)((seg * PX_SEG_CH + lc) * 16 + n) * 4u : OOR, 0, 0);
+      const int ck = 4 * (wave + NW * t) + lane;  // lanes 0..3: the block's four offset bytes
+      const int segk = ck < n0 ? 0 : (ck < n01 ? 1 : 2);
+      const int lck = ck - (ck < n0 ? 0 : (ck < n01 ? n0 : n01));
+      kv = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsK, (lane < 4 && t < nbw && ck < nch) ? (uint32_t)(segk * 112 + lck) : OOR, 0, 0);
     };
-    auto issue = [&](PxOperands<G> &r, const PxEntries<G> &x, int i) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int c = wave + NW * (i * G + g);
-        r.e[g] = c < nch ? x.ev[g] : PX_PAD;
+    auto issue = [&](PxOperands<1> &r, uint32_t ev, uint32_t kv, int t, int j) {
+      const bool on = t < nbw && 4 * (wave + NW * t) + j < nch;  // wave-uniform
+      const uint32_t ew = (uint32_t)__shfl((int)ev, 16 * j + n, 64);
+      r.e[0] = on ? ew : PX_PAD;
 #if defined(PX_ABLATE_B)
-        const uint32_t wk = 0x80000000u;
+      const uint32_t wk = 0x80000000u;
 #else
-        const uint32_t wk = c < nch ? x.kv[g] * kwbytes : 0x80000000u;
+      const uint32_t wk = on ? (uint32_t)__builtin_amdgcn_readlane((int)kv, j) * kwbytes : 0x80000000u;
 #endif
 #if defined(PX_ABLATE_A)
-        const uint32_t ioff = OOR;
+      const uint32_t ioff = OOR;
 #else
-        const uint32_t ioff = r.e[g] == PX_PAD ? OOR : (r.e[g] >> 6) * ldi4;
+      const uint32_t ioff = r.e[0] == PX_PAD ? OOR : (r.e[0] >> 6) * ldi4;
 #endif
-        if (W128) {
-          r.va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
-          r.vb[g] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wk + wk128, 0, 0);
+      if (W128) {
+        if (QUAD) {
+          // quad-contiguous gather: lane l fetches unit l & 3 of pair l >> 2, so the four lanes of a quad read ONE 64-byte
+          // run (16 cache accesses per wave-load instead of 64); compute() moves the words to the MFMA layout with
+          // ds_bpermute.  Measured: block7.conv1 (C_in = 24) 25.0 -> 22.2 us, block8.conv1 (C_in = 16) 31.8 -> 33.6 us --
+          // only the C_in = 24 instantiation uses it
+          const uint32_t eq = (uint32_t)__shfl((int)ev, 16 * j + (lane >> 2), 64);
+#if defined(PX_ABLATE_A)
+          const uint32_t ioq = OOR;
+#else
+          const uint32_t ioq = (!on || eq == PX_PAD) ? OOR : (eq >> 6) * ldi4;
+#endif
+          r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioq + (uint32_t)(lane & 3) * 16u, 0, 0);
+        } else {
+          r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
         }
-        if (W64) {
-          r.xa[g] = __builtin_amdgcn_raw_buffer_load_b64(rsA, ioff + ga64, 0, 0);
-          r.xb[g] = __builtin_amdgcn_raw_buffer_load_b64(rsW, wk + wk64, 0, 0);
-        }
+        r.vb[0] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wk + wk128, 0, 0);
+      }
+      if (W64) {
+        r.xa[0] = __builtin_amdgcn_raw_buffer_load_b64(rsA, ioff + ga64, 0, 0);
+        r.xb[0] = __builtin_amdgcn_raw_buffer_load_b64(rsW, wk + wk64, 0, 0);
       }
     };
-    auto compute = [&](const PxOperands<G> &r) {
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        const int orow = r.e[g] == PX_PAD ? 64 : (int)(r.e[g] & 63u);
-        floatx4 *ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
-        floatx4 cur = floatx4{0.f, 0.f, 0.f, 0.f};
+    auto compute = [&](const PxOperands<1> &r) {
+      const int orow = r.e[0] == PX_PAD ? 64 : (int)(r.e[0] & 63u);
+      floatx4 *ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
+      floatx4 cur = floatx4{0.f, 0.f, 0.f, 0.f};
 #if !defined(PX_ABLATE_RMW)
-        if (rmw) cur = *ap;
+      if (rmw) cur = *ap;
 #endif
-        floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
+      floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
 #if defined(PX_ABLATE_MFMA)
-        if (W128) d = floatx4{__uint_as_float(r.vb[g].x ^ r.va[g].x), __uint_as_float(r.vb[g].y ^ r.va[g].y), __uint_as_float(r.vb[g].z ^ r.va[g].z), __uint_as_float(r.vb[g].w ^ r.va[g].w)};
-        if (W64) d.x += __uint_as_float(r.xb[g].x ^ r.xa[g].x), d.y += __uint_as_float(r.xb[g].y ^ r.xa[g].y);
+      if (W128) d = floatx4{__uint_as_float(r.vb[0].x ^ r.va[0].x), __uint_as_float(r.vb[0].y ^ r.va[0].y), __uint_as_float(r.vb[0].z ^ r.va[0].z), __uint_as_float(r.vb[0].w ^ r.va[0].w)};
+      if (W64) d.x += __uint_as_float(r.xb[0].x ^ r.xa[0].x), d.y += __uint_as_float(r.xb[0].y ^ r.xa[0].y);
 #else
-        if (W128) {
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].x), __uint_as_float(r.va[g].x), d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].y), __uint_as_float(r.va[g].y), d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].z), __uint_as_float(r.va[g].z), d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[g].w), __uint_as_float(r.va[g].w), d, 0, 0, 0);
+      if (W128) {
+        uint32_t ax = r.va[0].x, ay = r.va[0].y, az = r.va[0].z, aw = r.va[0].w;
+        if (QUAD) {
+          const int src = 4 * n + q;  // lane (q, n) of the MFMA layout <- unit q of pair n = lane 4 n + q of the gather
+          ax = (uint32_t)__shfl((int)ax, src, 64), ay = (uint32_t)__shfl((int)ay, src, 64);
+          az = (uint32_t)__shfl((int)az, src, 64), aw = (uint32_t)__shfl((int)aw, src, 64);
         }
-        if (W64) {
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[g].x), __uint_as_float(r.xa[g].x), d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[g].y), __uint_as_float(r.xa[g].y), d, 0, 0, 0);
-        }
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[0].x), __uint_as_float(ax), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[0].y), __uint_as_float(ay), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[0].z), __uint_as_float(az), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.vb[0].w), __uint_as_float(aw), d, 0, 0, 0);
+      }
+      if (W64) {
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[0].x), __uint_as_float(r.xa[0].x), d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[0].y), __uint_as_float(r.xa[0].y), d, 0, 0, 0);
+      }
 #endif
 #if defined(PX_ABLATE_RMW)
-        if (rmw && r.e[g] == 0x12345u) *ap = cur + d;
+      if (rmw && r.e[0] == 0x12345u) *ap = cur + d;
 #else
-        if (rmw) *ap = cur + d;
+      if (rmw) *ap = cur + d;
 #endif
-      }
     };
-    if (ngrp > 0) {
-      // ring of NS operand sets: the loads of NS - 1 groups are in flight while one group computes; the rulebook words run
-      // another NS groups ahead.  Set j holds group i + j of the iteration; set (j + NS - 1) % NS is refilled before it.
-      PxEntries<G> x[NS];
-      PxOperands<G> r[NS];
-#pragma unroll
-      for (int j = 0; j < NS; ++j) fetch(x[j], j);
-#pragma unroll
-      for (int j = 0; j < NS - 1; ++j) {
-        issue(r[j], x[j], j);
-        fetch(x[j], j + NS);
-      }
-      for (int i = 0; i < ngrp; i += NS) {
-#pragma unroll
-        for (int j = 0; j < NS; ++j) {
-          const int s2 = (j + NS - 1) % NS;
-          issue(r[s2], x[s2], i + j + NS - 1);
-          fetch(x[s2], i + j + 2 * NS - 1);
-          if (i + j < ngrp) compute(r[j]);
-        }
+    if (nbw > 0) {
+      uint32_t ev0, kv0, ev1, kv1;
+      PxOperands<1> r0, r1;
+      fetch(ev0, kv0, 0);
+      fetch(ev1, kv1, 1);
+      issue(r0, ev0, kv0, 0, 0);
+      for (int t = 0; t < nbw; ++t) {  // block t in (ev0, kv0), block t + 1 in (ev1, kv1); chunk (t, 0) already issued into r0
+        issue(r1, ev0, kv0, t, 1);
+        compute(r0);
+        issue(r0, ev0, kv0, t, 2);
+        compute(r1);
+        issue(r1, ev0, kv0, t, 3);
+        compute(r0);
+        issue(r0, ev1, kv1, t + 1, 0);
+        compute(r1);
+        ev0 = ev1, kv0 = kv1;
+        fetch(ev1, kv1, t + 2);
       }
     }
     PX_STAMP(4);

@@ -92,16 +92,16 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_W4
 #define SPS_W4 4
 #endif
-// pair-exact conv (k_conv_px): waves per supertile, chunks per pipeline group, operand sets of the pipeline -- level 0 (thousands of supertiles: every
+// pair-exact conv (k_conv_px): waves per supertile -- level 0 (thousands of supertiles: every
 // workgroup resident at once) and the coarser levels (few supertiles: short chains); min waves / SIMD; default level mask
 #ifndef SPS_PX0
-#define SPS_PX0 4, 1, 2
+#define SPS_PX0 4
 #endif
 #ifndef SPS_PX0_W
 #define SPS_PX0_W 7
 #endif
 #ifndef SPS_PX1
-#define SPS_PX1 8, 1, 2
+#define SPS_PX1 8
 #endif
 #ifndef SPS_PX1_W
 #define SPS_PX1_W 4
@@ -532,9 +532,9 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   return g;
 }
 
-template <int NW, int G, int NS, int CIN, bool C8, bool DS, bool FIN, int MINW>
+template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW>
 void launch_px(dim3 grid, hipStream_t st, const ConvArgs &a) {
-  hipLaunchKernelGGL((k_conv_px<NW, G, NS, CIN, C8, DS, FIN, MINW>), grid, dim3(NW * 64), 0, st, a);
+  hipLaunchKernelGGL((k_conv_px<NW, CIN, C8, DS, FIN, MINW>), grid, dim3(NW * 64), 0, st, a);
 }
 
 // k_conv instantiation for a launch geometry (column tiles per wave x splits) -- shared by inference and training
