@@ -69,6 +69,14 @@ int sps_reserve(sps_ctx *ctx, int64_t max_points);
  * (re-allocation: synchronises).  sps_arena_bytes: device bytes the context's arena holds. */
 int sps_ctx_set_level_fractions(sps_ctx *ctx, const float *frac);
 int64_t sps_arena_bytes(sps_ctx *ctx);
+/* Inference-only context (streaming callers: sps_amd.engine.ScanEngine).  The one-column-tile 3x3x3x3 layers of levels 0 and 1
+ * run on the map's RULEBOOK (per 64-row supertile and offset the compacted (output row, input row) pairs; the counterpart of
+ * ME's kernel map, in / out index lists per offset), which k_maps builds next to the output-stationary neighbour table.
+ * on != 0: at those levels the rulebook takes the place AND the memory of the neighbour table, which is then neither written
+ * nor kept (17 MB less to store per config-2 scan, 324 B per row less arena): sps_get_nbr fails there, sps_get_map_pairs
+ * counts from the rulebook, and sps_train_forward switches the context back (re-allocation).  Takes effect at the next
+ * reserve / forward (re-allocation: synchronises). */
+int sps_ctx_set_inference_only(sps_ctx *ctx, int on);
 
 /* ---- weights ------------------------------------------------------------------------
  * Replaces nn.Module.load_state_dict on CustomMinkUNet (reference scripts/predict.py:56-58,

@@ -153,7 +153,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
         const unsigned long long bal = __ballot(row >= 0);
         const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
         // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
-        if (any && ok) nbr[(size_t)(27 * slice + j) * ldn + u] = row;
+        if (any && ok && nbr) nbr[(size_t)(27 * slice + j) * ldn + u] = row;  // (inference-only contexts keep no table here)
         m |= any ? 1u << j : 0u;
         if (eb) {  // wave-uniform
           const int cnt = __popcll(bal);
@@ -252,6 +252,24 @@ __global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int nchunk, int n_nbr
     build_nbr3(ma, bid % nchunk, bid / nchunk);
   else
     build_stride_maps(ma, bid - n_nbr);
+}
+
+// pairs per offset from the rulebook (inference-only contexts keep no neighbour table at the pair-exact levels):
+// one thread per chunk slot of every (supertile, time slice) segment
+__global__ void k_count_pairs_rb(const uint32_t *__restrict__ rb_e, const unsigned char *__restrict__ rb_k,
+                                 const int *__restrict__ rb_cnt, const int *__restrict__ n_ptr,
+                                 unsigned long long *__restrict__ pairs) {
+  const int nst = (*n_ptr + 63) >> 6;
+  const int64_t total = (int64_t)nst * 3 * PX_SEG_CH;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int st = (int)(i / (3 * PX_SEG_CH)), r = (int)(i - (int64_t)st * (3 * PX_SEG_CH));
+    const int seg = r / PX_SEG_CH, lc = r - seg * PX_SEG_CH;
+    if (lc >= rb_cnt[(size_t)st * 4 + seg]) continue;
+    const uint32_t *e = rb_e + ((size_t)st * PX_CH_MAX + (size_t)seg * PX_SEG_CH + lc) * 16;
+    int c = 0;
+    for (int j = 0; j < 16; ++j) c += e[j] != PX_PAD;
+    atomicAdd(&pairs[rb_k[(size_t)st * PX_KSTRIDE + seg * 112 + lc]], (unsigned long long)c);
+  }
 }
 
 __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slice_words, const int *__restrict__ n_ptr,

@@ -204,6 +204,9 @@ struct sps_ctx {
   int64_t hash_slots = 0;  // sum of hcapl
   float lfrac[SPS_NUM_LEVELS] = {1.f, 1.f, 1.f, 1.f, 1.f};
   bool compact = false, regrow = false;
+  // inference-only context (sps_ctx_set_inference_only): at the levels whose layers run pair-exact the rulebook takes
+  // the place (and the memory) of the neighbour table, which is neither written nor kept -- no training, no sps_get_nbr
+  bool lean = false;
   uint64_t arena_gen = 0;  // bumped by every (re)allocation of the arena: dependants (training views) re-derive their pointers
   int64_t last_n = 0;    // points of the last forward
   bool have_weights = false;
@@ -350,7 +353,13 @@ int reserve(sps_ctx *c, int64_t n) {
       ALLOC(L.nbr3, int, 81 * rows);
       L.rb_e = nullptr, L.rb_k = nullptr, L.rb_cnt = nullptr;
       if (l < PX_LEVELS && ((px_levels() >> l) & 1)) {  // capacities are multiples of 1024
-        ALLOC(L.rb_e, uint32_t, (rows / 64) * (int64_t)(PX_CH_MAX * 16));
+        static_assert(PX_CH_MAX * 16 == 81 * 64, "a supertile's rulebook is as large as its 64 rows of the neighbour table");
+        if (c->lean) {
+          L.rb_e = reinterpret_cast<uint32_t *>(L.nbr3);
+          L.nbr3 = nullptr;
+        } else {
+          ALLOC(L.rb_e, uint32_t, (rows / 64) * (int64_t)(PX_CH_MAX * 16));
+        }
         ALLOC(L.rb_k, unsigned char, (rows / 64) * (int64_t)PX_KSTRIDE);
         ALLOC(L.rb_cnt, int, (rows / 64) * 4);
       }
@@ -662,7 +671,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   }
   const bool ds = cs.ds_cin > 0;
   // one-column-tile layers over a 3x3x3x3 map: pair-exact kernel over the level's rulebook (k_conv_px)
-  if (cc.level_out < PX_LEVELS && ((px_levels() >> cc.level_out) & 1) && c->lv[cc.level_out].rb_e && cs.K == 81 && a.NT == 1 && a.nbr && a.tmask && (cs.cout == 8 || cs.cout == 16) &&
+  if (cc.level_out < PX_LEVELS && ((px_levels() >> cc.level_out) & 1) && c->lv[cc.level_out].rb_e && cs.K == 81 && a.NT == 1 && (cs.cout == 8 || cs.cout == 16) &&
       (cs.cin == 8 || cs.cin == 16 || cs.cin == 24) && (!cc.fin || cs.cout == 8)) {
     int64_t gs = (c->cap / 64) >> cc.level_out;  // expected supertiles at this level
     if (gs < 64) gs = 64;
@@ -693,6 +702,9 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
 #undef SPS_PX_LAUNCH
     return SPS_OK;
   }
+  if (cs.K == 81 && !a.nbr)
+    return fail(SPS_ERR_INVALID, "%s has no pair-exact instantiation and the inference-only context keeps no neighbour table at level %d",
+                cc.name, cc.level_out);
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
   if (cc.fin) {
     hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
@@ -1279,6 +1291,16 @@ int sps_check(sps_ctx *c, void *stream) {
   return report_device_errors(c, e, st);
 }
 
+int sps_ctx_set_inference_only(sps_ctx *c, int on) {
+  if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
+  const bool lean = on != 0;
+  if (lean != c->lean) {
+    c->lean = lean;
+    if (c->cap > 0) c->regrow = true;  // re-allocated by the next reserve / forward
+  }
+  return SPS_OK;
+}
+
 int sps_ctx_set_level_fractions(sps_ctx *c, const float *frac) {
   if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
   bool compact = false;
@@ -1624,6 +1646,16 @@ int sps_get_map_pairs(sps_ctx *c, int which, int64_t *pairs_host) {
   const int level = which == 5 ? 0 : which;
   if (which == 5 && !c->nbr5 && c->cap > 0) ALLOC(c->nbr5, int, 125 * c->cap);
   const int *nbr = which == 5 ? c->nbr5 : c->lv[which].nbr3;
+  if (which < 5 && !nbr) {  // inference-only context: the level's rulebook holds the same pairs
+    const Level &L = c->lv[which];
+    if (!L.rb_e) return fail(SPS_ERR_INVALID, "level %d has neither a neighbour table nor a rulebook", which);
+    HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_count_pairs_rb, dim3(1024), dim3(256), 0, 0, L.rb_e, L.rb_k, L.rb_cnt, c->counts + which, c->pairs);
+    unsigned long long hr[128];
+    HIP_TRY(hipMemcpy(hr, c->pairs, sizeof hr, hipMemcpyDeviceToHost));
+    for (int k = 0; k < K; ++k) pairs_host[k] = (int64_t)hr[k];
+    return SPS_OK;
+  }
   if (which == 5) HIP_TRY(hipMemset(c->tm5, 0, (size_t)(c->cap / 16) * 4 * sizeof(uint32_t)));
   if (which == 5)  // debug only: materialise the 5x5x5x1 table from the (still valid) block tables
     hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0,
@@ -1653,6 +1685,8 @@ int sps_get_tile_masks(sps_ctx *c, int which, uint32_t *masks_dev, int64_t *n_ti
 
 int sps_get_nbr(sps_ctx *c, int which, int32_t *nbr_dev) {
   if (!c || !nbr_dev || which < 0 || which > 4) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!c->lv[which].nbr3)
+    return fail(SPS_ERR_INVALID, "an inference-only context keeps no neighbour table at level %d (sps_ctx_set_inference_only)", which);
   int64_t cnt[SPS_NUM_LEVELS];
   int rc = sps_level_counts(c, cnt);
   if (rc != SPS_OK) return rc;

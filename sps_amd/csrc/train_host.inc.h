@@ -388,6 +388,10 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
     c->compact = false;
     if (c->cap > 0) c->regrow = true;
   }
+  if (c->lean) {  // the training convolutions and weight gradients read the neighbour tables of every level
+    c->lean = false;
+    if (c->cap > 0) c->regrow = true;
+  }
   // coordinate structures: the inference front-end with the network skipped (weights are not needed for it)
   {
     ForwardOpts fo;

@@ -45,6 +45,9 @@ class ScanEngine:
         if self.compact:
             for cx in self.ctxs:
                 cx.set_level_fractions(cx.LIDAR_FRACTIONS)
+        # the engine only runs inference: the rulebook replaces the neighbour table where the layers run pair-exact
+        for cx in self.ctxs:
+            cx.set_inference_only(True)
         self._next = 0
         self._stage = [None] * S          # per-stream device staging buffer for host batches
         self._pinned = [None] * S

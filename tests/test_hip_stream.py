@@ -315,3 +315,33 @@ def test_compact_arena_overflow_aborts_reports_and_recovers(net, params):
     np.testing.assert_array_equal(sums[0, :5], sums[2, :5])
     np.testing.assert_allclose(sums[0, 5:], sums[2, 5:], rtol=1e-12)     # f64 atomics: order-dependent rounding
     assert not eng.compact                                           # fell back to full-size arenas
+
+
+@pytest.mark.gpu
+def test_inference_only_context_rulebook_replaces_neighbour_table(net):
+    """sps_ctx_set_inference_only: at the pair-exact levels the rulebook takes the neighbour table's memory; scores are
+    bit-identical, the pair counts (now counted from the rulebook) are the same, sps_get_nbr refuses, and the arena shrinks."""
+    from sps_amd import _native
+    from sps_amd.models.models import get_context
+    batch = torch.from_numpy(synthetic.small_scene(seed=23, n_scan=2400)).cuda()
+    st = torch.cuda.Stream()
+    cx = get_context(0, st.cuda_stream)
+    cx.set_inference_only(False)
+    with torch.cuda.stream(st):
+        ref = net(batch).clone()
+    st.synchronize()
+    pairs_full = [cx.map_pairs(l) for l in range(5)]
+    bytes_full = cx.arena_bytes()
+    cx.set_inference_only(True)
+    with torch.cuda.stream(st):
+        out = net(batch).clone()
+    st.synchronize()
+    assert torch.equal(out, ref)
+    assert [cx.map_pairs(l) for l in range(5)] == pairs_full
+    assert cx.arena_bytes() < bytes_full
+    V = cx.level_counts()
+    nb = torch.empty((81, V[0]), dtype=torch.int32, device="cuda")
+    assert _native.lib.sps_get_nbr(cx.handle, 0, nb.data_ptr()) != 0          # no table at a pair-exact level ...
+    nb4 = torch.empty((81, V[4]), dtype=torch.int32, device="cuda")
+    assert _native.lib.sps_get_nbr(cx.handle, 4, nb4.data_ptr()) == 0         # ... the coarse levels keep theirs
+    cx.set_inference_only(False)

@@ -28,7 +28,7 @@ for d in sys.argv[1:]:
             for r in rs:
                 table[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
             continue
-        if "k_conv<" in kn:
+        if "k_conv<" in kn or "k_conv_px<" in kn:
             conv_i += 1
             key = names[conv_i] if 0 <= conv_i < len(names) else f"conv{conv_i}"
             for r in rs:
