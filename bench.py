@@ -293,7 +293,7 @@ def main():
     work = roofline.algorithmic_work(n_points, V, pairs3, pairs5)
     t_step = gpu_ms * 1e-3 / K
     achieved = work["bytes"] / t_step / 1e9
-    stages, dom = [], None
+    stages, dom, dom_bytes = [], None, None
     if not args.no_stages:
         # per-stage breakdown (separate serial pass with one hipEvent after every kernel stage, on the launch stream)
         ctx.profile_enable(True)
@@ -312,10 +312,15 @@ def main():
             if pl and acc[name] > 0:
                 gbs = pl["bytes"] / (acc[name] * 1e-3) / 1e9
                 tf = pl["flops"] / (acc[name] * 1e-3) / 1e12
-                entry.update(alg_bytes=pl["bytes"], alg_gbs=round(gbs, 1), hbm_frac=round(gbs / roofline.HBM_PEAK_GBS, 4),
-                             alg_tflops=round(tf, 2), mfma_f32_frac=round(tf / roofline.MFMA_F32_PEAK_TFLOPS, 4))
+                hf, mf = gbs / roofline.HBM_PEAK_GBS, tf / roofline.MFMA_F32_PEAK_TFLOPS
+                # the roof that binds this layer = the longer of its two floors (bytes / 8 TB/s, flops / 157.3 TF)
+                entry.update(alg_bytes=pl["bytes"], alg_gbs=round(gbs, 1), hbm_frac=round(hf, 4),
+                             alg_tflops=round(tf, 2), mfma_f32_frac=round(mf, 4),
+                             roof_bound="hbm" if hf >= mf else "mfma", roof_frac=round(max(hf, mf), 4))
             stages.append(entry)
-        dom = max((s for s in stages if s["stage"] in work["per_layer"]), key=lambda s: s["ms"])
+        layer_stages = [s for s in stages if s["stage"] in work["per_layer"]]
+        dom = max(layer_stages, key=lambda s: s["ms"])                      # longest kernel stage
+        dom_bytes = max(layer_stages, key=lambda s: s.get("alg_bytes", 0))   # most algorithmic bytes (HBM-shaped)
     # HBM bytes per scan from PMC passes (tools/traffic_pmc.py): only if they were taken with THIS build of the kernels
     traffic, traffic_note = None, "not measured for this build"
     tp = os.path.join(ROOT, "profiles", "traffic.json")
@@ -334,7 +339,8 @@ def main():
         "gpu_ms_per_step": round(t_step * 1e3, 4),
         "frac_vs_measured_copy_6290": round(achieved / roofline.HBM_COPY_GBS, 5),
         "mfma_f32_frac": round(work["flops"] / t_step / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5),
-        "dominant_kernel": dom, "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
+        "dominant_kernel": dom, "largest_traffic_kernel": dom_bytes if stages else None,
+        "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
     }
 
     # ---- CPU baseline + parity: the oracle's C restatement on this box's host cores (checker only) ----

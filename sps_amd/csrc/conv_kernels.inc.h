@@ -502,16 +502,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       const bool on = t < nbw && 4 * (wave + NW * t) + j < nch;  // wave-uniform
       const uint32_t ew = (uint32_t)__shfl((int)ev, 16 * j + n, 64);
       r.e[0] = on ? ew : PX_PAD;
-#if defined(PX_ABLATE_B)
-      const uint32_t wk = 0x80000000u;
-#else
       const uint32_t wk = on ? (uint32_t)__builtin_amdgcn_readlane((int)kv, j) * kwbytes : 0x80000000u;
-#endif
-#if defined(PX_ABLATE_A)
-      const uint32_t ioff = OOR;
-#else
       const uint32_t ioff = r.e[0] == PX_PAD ? OOR : (r.e[0] >> 6) * ldi4;
-#endif
       if (W128) {
         if (QUAD) {
           // quad-contiguous gather: lane l fetches unit l & 3 of pair l >> 2, so the four lanes of a quad read ONE 64-byte
@@ -519,11 +511,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
           // ds_bpermute.  Measured: block7.conv1 (C_in = 24) 25.0 -> 22.2 us, block8.conv1 (C_in = 16) 31.8 -> 33.6 us --
           // only the C_in = 24 instantiation uses it
           const uint32_t eq = (uint32_t)__shfl((int)ev, 16 * j + (lane >> 2), 64);
-#if defined(PX_ABLATE_A)
-          const uint32_t ioq = OOR;
-#else
           const uint32_t ioq = (!on || eq == PX_PAD) ? OOR : (eq >> 6) * ldi4;
-#endif
           r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioq + (uint32_t)(lane & 3) * 16u, 0, 0);
         } else {
           r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
@@ -539,14 +527,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       const int orow = r.e[0] == PX_PAD ? 64 : (int)(r.e[0] & 63u);
       floatx4 *ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
       floatx4 cur = floatx4{0.f, 0.f, 0.f, 0.f};
-#if !defined(PX_ABLATE_RMW)
       if (rmw) cur = *ap;
-#endif
       floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
-#if defined(PX_ABLATE_MFMA)
-      if (W128) d = floatx4{__uint_as_float(r.vb[0].x ^ r.va[0].x), __uint_as_float(r.vb[0].y ^ r.va[0].y), __uint_as_float(r.vb[0].z ^ r.va[0].z), __uint_as_float(r.vb[0].w ^ r.va[0].w)};
-      if (W64) d.x += __uint_as_float(r.xb[0].x ^ r.xa[0].x), d.y += __uint_as_float(r.xb[0].y ^ r.xa[0].y);
-#else
       if (W128) {
         uint32_t ax = r.va[0].x, ay = r.va[0].y, az = r.va[0].z, aw = r.va[0].w;
         if (QUAD) {
@@ -563,12 +545,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[0].x), __uint_as_float(r.xa[0].x), d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[0].y), __uint_as_float(r.xa[0].y), d, 0, 0, 0);
       }
-#endif
-#if defined(PX_ABLATE_RMW)
-      if (rmw && r.e[0] == 0x12345u) *ap = cur + d;
-#else
       if (rmw) *ap = cur + d;
-#endif
     };
     if (nbw > 0) {
       uint32_t ev0, kv0, ev1, kv1;

@@ -11,6 +11,6 @@ for v in "$@"; do
   timeout -k 10 200 python bench.py --steps 300 --warmup 30 --no-cpu-baseline --no-h2d 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); st=d['roofline']['stages']
 print('   ', d['value'], 'scans/s', d['roofline']['gpu_ms_per_step'], 'ms  serial_sum', d['roofline']['stage_ms_sum'])
-print('   ', ' '.join(s['stage'].replace('block','b').replace('.0.conv','c').replace('conv','c')+':'+str(round(s['ms']*1000,1)) for s in st if s['stage'][:6] in ('maps','block1','block2','block7','block8')))"
+print('   ', ' '.join(s['stage'].replace('block','b').replace('.0.conv','c').replace('conv','c')+':'+str(round(s['ms']*1000,1)) for s in st if (s['stage'][:5] in ('maps', 'block')) or '$ALL_STAGES'))"
   unset SPS_LIB; rm -f $lib
 done
