@@ -104,7 +104,21 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
     # evaluated on one of the engine's streams; the 8 metric sums of every scan land in a device table; ONE
     # synchronisation at the end of the sequence.
     kw = {} if streams is None else {"streams": streams}
-    eng = ScanEngine(model, dev, table_rows=n_scans + batch_size, **kw)
+    # arenas and staging buffers of every stream are sized before the loop (largest group of the sequence when it is in
+    # memory, else batch_size x the first scan with 50 % head room; a larger cloud later only costs one re-allocation)
+    if isinstance(loader, list):
+        # the synthetic sequence is in memory: collate the groups now, into pinned tensors -- what the reference's DataLoader
+        # (batch_size, collate_fn, pin_memory=True; worker processes) hands to the loop
+        groups = []
+        for g in batched(loader, batch_size):
+            b = g[0] if len(g) == 1 else datasets.BacchusModule.collate_fn([x[:, 1:] for x in g])
+            groups.append((b.pin_memory() if (dev.type == "cuda" and not b.is_pinned()) else b, len(g)))
+        max_rows = max(int(b.shape[0]) for b, _ in groups) if groups else 0
+    else:
+        groups = None
+        first = next(iter(loader))
+        max_rows = int(first.shape[0] * batch_size * 1.5)
+    eng = ScanEngine(model, dev, table_rows=n_scans + batch_size, max_rows=max_rows, stage_cols=6, **kw)
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -113,12 +127,14 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
         idx = []                                          # scan index of every used table row
         eng.reset_table(n_scans + batch_size)
         with torch.no_grad():
-            for g, group in enumerate(batched(loader, batch_size)):
+            it = groups if groups is not None else (
+                (grp[0] if len(grp) == 1 else datasets.BacchusModule.collate_fn([b[:, 1:] for b in grp]), len(grp))
+                for grp in batched(loader, batch_size))
+            for g, (batch, ng) in enumerate(it):
                 if g % world != rank:                     # parallel.shard_indices over groups
                     continue
-                batch = group[0] if len(group) == 1 else datasets.BacchusModule.collate_fn([b[:, 1:] for b in group])
-                eng.submit(batch, len(group))
-                idx += [g * batch_size + j for j in range(len(group))]
+                eng.submit(batch, ng)
+                idx += [g * batch_size + j for j in range(ng)]
         try:
             sums = eng.finish()
             break
