@@ -143,6 +143,8 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
             # aborted): evaluate the sequence again on full-size arenas
             if e.code != ERR_NOMEM or attempt:
                 raise
+            if rank == 0:
+                print("a cloud outgrew the LiDAR-sized arenas: evaluating the sequence again on full-size arenas", file=sys.stderr)
             eng.use_full_arenas()
     n_local = len(idx)
     local_rows = torch.empty((n_local, parallel.ROW), dtype=torch.float64, device=dev)
