@@ -142,14 +142,19 @@ def main():
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
     ap.add_argument("--seq-scans", type=int, default=32, help="config 3: distinct scans of the sequence (cycled)")
     ap.add_argument("--scenes", type=int, default=4, help="config 2: distinct scans cycled through the steps")
-    ap.add_argument("--streams", type=int, default=23,
+    ap.add_argument("--streams", type=int, default=7,
                     help="independent steps in flight per GPU (one HIP stream + native context each); 1 = strictly serial. "
-                         "Clamped to --steps.  The HIP runtime multiplexes streams onto 4 hardware queues: counts of the "
-                         "form 4k+3 measure 5-15 %% above their neighbours (DESIGN.md section 4)")
+                         "Default 7 = the knee of the stream sweep (DESIGN.md section 3.2: 3 streams reach 96 %% of the best "
+                         "rate, 7 reach 99 %%, 23 cost 3x the arena memory for +1 %%).  Short runs use fewer so that every stream "
+                         "executes about three timed steps.  The HIP runtime multiplexes streams onto 4 hardware queues: counts "
+                         "of the form 4k+3 measure 5-15 %% above their neighbours")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank control flow on a single GPU)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the metric all-gather even at "
+                    "world size 1 (under torchrun --nproc-per-node 1): executes the RCCL path on a single-GPU box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-h2d", action="store_true", help="skip the second (host-buffer-fed) timed region")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer-fed timed region: `value` is then the "
+                    "resident-input rate (diagnostic runs; the headline includes the copy, SURVEY 8(d))")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-layer hipEvent pass")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--order", default="scan", choices=["scan", "morton"],
@@ -171,7 +176,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
@@ -211,7 +216,11 @@ def main():
             net.model.mark_weights_dirty()
 
     # ---- engine: arena + shared weights + one forward per context, all before the timed region -------------------
+    # every stream should execute ~3 timed steps (a run of K steps on K streams measures the fill + drain of K one-step
+    # pipelines): K = 20 -> 7 streams, K < 18 -> 3
     S = max(1, min(args.streams, K))
+    if S > 3 and K < 2.5 * S:
+        S = 7 if (args.streams >= 7 and K >= 18) else 3
     eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb, stage_cols=0 if args.no_h2d else 6)
     streams = eng.streams
     main_stream = eng.main
@@ -258,16 +267,24 @@ def main():
         eng.finish()                          # sticky device errors (coordinate range) surface here
         return float(el.item()), gpu_ms, gathered, scores
 
-    elapsed, gpu_ms, gathered, scores = timed_region(batches)
+    # Headline ("H2D of the input included"): every step's [N,6] batch is copied from a pinned host buffer to the
+    # device on the step's stream INSIDE the timed region.  The same K steps with the inputs already resident in HBM
+    # are measured next to it (`resident_inputs`).
+    res_el, res_gpu, res_gathered, res_scores = timed_region(batches)
+    res_issue_ms = issue_s[0] / K * 1e3
+    resident = {"value": round(K * nb * world / res_el, 2), "unit": "scans/s", "ms_per_step": round(res_el / K * 1e3, 4),
+                "gpu_ms_per_step": round(res_gpu / K, 4), "host_issue_ms_per_step": round(res_issue_ms, 4),
+                "note": "same K steps, inputs already resident in HBM when the timed region starts"}
+    if args.no_h2d:
+        elapsed, gpu_ms, gathered, scores, inputs = res_el, res_gpu, res_gathered, res_scores, "resident in HBM (--no-h2d: diagnostic)"
+    else:
+        elapsed, gpu_ms, gathered, scores = timed_region(pinned)
+        inputs = "pinned host buffer -> device copy of every step's [N,6] batch inside the timed region"
     host_issue_ms = issue_s[0] / K * 1e3
     rows_resident = (torch.cat(gathered, 0) if gathered is not None else eng.table[: K * nb]).cpu().numpy().copy()
-    h2d = None
-    if not args.no_h2d:
-        el2, gpu2, _, _ = timed_region(pinned)
-        h2d = {"value": round(K * nb * world / el2, 2), "unit": "scans/s", "ms_per_step": round(el2 / K * 1e3, 4),
-               "gpu_ms_per_step": round(gpu2 / K, 4), "bytes_per_step": int(batches_np[0].nbytes),
-               "note": "same K steps, every step's [N,6] batch copied from a pinned host buffer on the step's stream "
-                       "inside the timed region (SURVEY 8(d)); never the headline value"}
+    h2d = {"value": round(K * nb * world / elapsed, 2), "unit": "scans/s", "ms_per_step": round(elapsed / K * 1e3, 4),
+           "gpu_ms_per_step": round(gpu_ms / K, 4), "bytes_per_step": int(batches_np[0].nbytes),
+           "note": "= the headline `value`"} if not args.no_h2d else None
 
     if rank != 0:
         if dist is not None:
@@ -412,7 +429,8 @@ def main():
                    "arena_mb_all_contexts": round(sum(cx.arena_bytes() for cx in eng.ctxs) / 2**20, 1),
                    "compact_arenas": eng.compact},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,
-        "mean_confusion": confusion, "h2d_inclusive": h2d, "host_cores": os.cpu_count(),
+        "mean_confusion": confusion, "inputs": inputs, "resident_inputs": resident, "h2d_inclusive": h2d,
+        "host_cores": os.cpu_count(),
         "host_issue_ms_per_step": round(host_issue_ms, 4),
     }
     print(json.dumps(out))

@@ -229,6 +229,27 @@ int sps_radius_count(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64
 int sps_radius_fill(sps_ctx *ctx, const double *scan_xyz_dev, int64_t ld, int64_t n, const int64_t *offsets_dev,
                     int64_t *out_idx_dev, void *stream);
 
+/* A second context of the same device uses the owner's radius grid without a copy (a view: the owner keeps and frees
+ * the allocations and must outlive it).  The S pipelined contexts of one evaluation loop share ONE grid this way. */
+int sps_radius_grid_attach(sps_ctx *ctx, sps_ctx *owner);
+/* The whole offline item on the device, stream-ordered, no host synchronisation: replaces BacchusDataset.__getitem__
+ * (reference src/sps/datasets/blt_dataset.py:209-244: scan rows + add_timestamp + select_closest_points + map rows) and
+ * the batch column of BacchusModule.collate_fn (:173-182).  scan_dev rows are (x, y, z, label) in the scan's own dtype
+ * (float64: in_f64 = 1, else float32, promoted to float64 for the radius test as cKDTree does), row stride ld >= 4.
+ * Writes into rows_dev (float32 [row_cap, ldo], ldo >= 6), starting at row *row_off_dev (NULL = 0):
+ *   n rows (b, x, y, z, 1, label)   then   m rows (b, mx, my, mz, 0, 1)
+ * with b = batch_index and the m map points within r of some scan point (one list per scan point, duplicates kept, as
+ * sps_radius_count / sps_radius_fill), and *n_rows_dev = *row_off_dev + n + m: chaining calls with
+ * row_off_dev = n_rows_dev appends the items of a batch.  Rows beyond row_cap are dropped and the next synchronising
+ * call (sps_check) returns SPS_ERR_NOMEM. */
+int sps_radius_item(sps_ctx *ctx, const void *scan_dev, int in_f64, int64_t ld, int64_t n, float batch_index,
+                    const int32_t *row_off_dev, float *rows_dev, int64_t ldo, int64_t row_cap, int32_t *n_rows_dev,
+                    void *stream);
+/* sps_forward_metrics whose row count is read from DEVICE memory (*n_dev <= n_max; grids are sized for n_max): the
+ * consumer of sps_radius_item in the offline loop (reference scripts/predict.py:64-67 -> models.py:84-111). */
+int sps_forward_metrics_n(sps_ctx *ctx, const float *batch_dev, int64_t ld, int64_t n_max, const int32_t *n_dev,
+                          float voxel_size, float eps, int n_batches, float *scores_dev, double *out_dev, void *stream);
+
 /* ---- training step ---------------------------------------------------------
  * Replaces the forward + loss.backward() of SPSNet.training_step / common_step (reference
  * src/sps/models/models.py:62-82) for the network part; the loss (nn.MSELoss on the scan rows) and the optimiser
@@ -246,6 +267,19 @@ int sps_train_forward(sps_ctx *ctx, const float *params_dev, int64_t numel, cons
                       float voxel_size, float *scores_dev, float *batch_stats_dev, void *stream);
 int sps_train_backward(sps_ctx *ctx, const float *dscores_dev, const float *scores_dev, float *grad_dev, int64_t numel,
                        void *stream);
+/* The activations, kernel maps and parameter copy a backward reads live in ctx and belong to ONE forward: every forward
+ * of the context (training or inference) bumps its generation.  sps_train_generation returns the generation of the
+ * training forward whose activations are held (what torch keeps in the autograd node, sps_amd/models/models.py
+ * ::_TrainForward); sps_train_backward_at is sps_train_backward that fails with SPS_ERR_INVALID when that forward's
+ * activations have been overwritten by a later forward (two graphs alive on one context, an evaluation forward
+ * issued mid-step) instead of returning gradients of the wrong forward.  sps_train_backward itself refuses a backward
+ * after an intervening inference forward.
+ * Train-mode BatchNorm needs more than one active row per level (nn.BatchNorm1d raises "Expected more than 1 value per
+ * channel when training", reference resnet.py:100-107): a training forward whose coarsest level has a single voxel sets a
+ * sticky flag and the next synchronising call (sps_check) returns SPS_ERR_INVALID. */
+int sps_train_generation(sps_ctx *ctx, int64_t *generation);
+int sps_train_backward_at(sps_ctx *ctx, int64_t generation, const float *dscores_dev, const float *scores_dev,
+                          float *grad_dev, int64_t numel, void *stream);
 
 /* ---- per-stage timing (hipEvents on the caller's stream; for bench.py / DESIGN.md) ------
  * With profiling on, sps_forward records one event after every stage ("reset", "voxelize",

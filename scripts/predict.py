@@ -8,6 +8,8 @@ Differences, on purpose:
   * ``--sequence`` is taken as ONE sequence id (the reference wraps the string in list(), which splits
     it into characters and trips its own assert, predict.py:44-48);
   * ``--synthetic N`` evaluates N synthetic scans (no $DATA tree / checkpoint exist in this environment);
+  * the per-scan item (scan rows + KD-tree radius submap, blt_dataset.py:209-271) is assembled ON THE DEVICE from the
+    cached scans (sps_radius_item; ``--host-items`` keeps the reference's DataLoader + scipy cKDTree path);
   * launched under ``python -m torch.distributed.run --nproc-per-node W`` the scans are sharded
     i mod W over the GPUs and the per-scan metric rows are all-gathered once (RCCL).
 """
@@ -64,7 +66,10 @@ def batched(loader, k):
                    "amortises the per-launch costs: ~15 %% more scans/s than 1")
 @click.option("--streams", type=int, default=None, help="forwards in flight (HIP streams); default: the engine's")
 @click.option("--timing", is_flag=True, help="print scans/s of the evaluation loop (rank 0)")
-def main(weights, sequence, config, n_synth, batch_size, streams, timing):
+@click.option("--force-dist", is_flag=True, help="initialise the process group (RCCL) and all-gather the metric rows even at world size 1")
+@click.option("--host-items", is_flag=True, help="assemble the items on the host (DataLoader workers + scipy cKDTree, as the "
+                                                 "reference does) instead of on the device")
+def main(weights, sequence, config, n_synth, batch_size, streams, timing, force_dist, host_items):
     cfg = yaml.safe_load(open(config))
     if sequence:
         cfg["DATA"]["SPLIT"]["TEST"] = [sequence]
@@ -77,16 +82,22 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or force_dist
+    if use_dist:
         import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    raw_scans = None
     if n_synth:
         loader = list(synthetic_scans(n_synth, cfg["MODEL"]["VOXEL_SIZE"]))
     else:
-        data = datasets.BacchusModule(cfg, test=True)
-        data.setup()
-        loader = data.test_dataloader()
+        data = datasets.BacchusModule(cfg, test=True)           # $DATA tree -> cached scans in the map frame + the map
+        if host_items:
+            data.setup()                                        # KD-tree of the map, DataLoader (blt_dataset.py:102-118,198)
+            loader = data.test_dataloader()
+        else:
+            raw_scans = loader = data.test_scans                # the items are assembled on the device (no KD-trees at all)
     n_scans = len(loader)
 
     if not weights:
@@ -106,7 +117,10 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
     kw = {} if streams is None else {"streams": streams}
     # arenas and staging buffers of every stream are sized before the loop (largest group of the sequence when it is in
     # memory, else batch_size x the first scan with 50 % head room; a larger cloud later only costs one re-allocation)
-    if isinstance(loader, list):
+    if raw_scans is not None:
+        groups = None
+        max_rows = 0
+    elif isinstance(loader, list):
         # the synthetic sequence is in memory: collate the groups now, into pinned tensors -- what the reference's DataLoader
         # (batch_size, collate_fn, pin_memory=True; worker processes) hands to the loop
         groups = []
@@ -119,6 +133,11 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
         first = next(iter(loader))
         max_rows = int(first.shape[0] * batch_size * 1.5)
     eng = ScanEngine(model, dev, table_rows=n_scans + batch_size, max_rows=max_rows, stage_cols=6, **kw)
+    if raw_scans is not None:
+        # the map goes to the device once (uniform cell grid of the radius query); buffers and arenas of every stream are
+        # sized for the largest group of the sequence before the loop
+        eng.attach_map(data.map[:, :3], cfg["MODEL"]["VOXEL_SIZE"])
+        eng.prepare_scans(max(sum(len(s) for s in g) for g in batched(raw_scans, batch_size)), raw_scans[0].dtype)
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -127,7 +146,13 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
         idx = []                                          # scan index of every used table row
         eng.reset_table(n_scans + batch_size)
         with torch.no_grad():
-            it = groups if groups is not None else (
+            if raw_scans is not None:
+                for g, grp in enumerate(batched(raw_scans, batch_size)):
+                    if g % world != rank:
+                        continue
+                    eng.submit_scans(grp)
+                    idx += [g * batch_size + j for j in range(len(grp))]
+            it = () if raw_scans is not None else groups if groups is not None else (
                 (grp[0] if len(grp) == 1 else datasets.BacchusModule.collate_fn([b[:, 1:] for b in grp]), len(grp))
                 for grp in batched(loader, batch_size))
             for g, (batch, ng) in enumerate(it):
@@ -144,13 +169,15 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
             if e.code != ERR_NOMEM or attempt:
                 raise
             if rank == 0:
-                print("a cloud outgrew the LiDAR-sized arenas: evaluating the sequence again on full-size arenas", file=sys.stderr)
+                print("a cloud outgrew the LiDAR-sized arenas or the item buffers: evaluating the sequence again on full-size "
+                      "arenas and larger item buffers", file=sys.stderr)
             eng.use_full_arenas()
+            eng.row_factor *= 2.0
     n_local = len(idx)
     local_rows = torch.empty((n_local, parallel.ROW), dtype=torch.float64, device=dev)
     local_rows[:, 0] = torch.tensor(idx, dtype=torch.float64, device=dev)
     local_rows[:, 1:] = sums[:n_local]
-    gathered = parallel.gather_metric_rows(local_rows, world)      # one RCCL all-gather per sequence
+    gathered = parallel.gather_metric_rows(local_rows, world, force=use_dist)      # one RCCL all-gather per sequence
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
@@ -164,7 +191,7 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing):
         if timing:
             print(f"timing: {len(gathered)} scans in {dt:.3f} s = {len(gathered) / dt:.1f} scans/s "
                   f"({world} GPU(s), {len(eng.streams)} streams, batch {batch_size}, host->device copies included)")
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

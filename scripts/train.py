@@ -69,12 +69,26 @@ def main(config, n_synth, max_epochs, out):
     torch.manual_seed(0)
 
     # Load data and model (train.py:33-35)
+    train_sampler = None          # set when every rank loads its own shard; else batch i -> rank i mod W of a common list
     if n_synth:
         train_loader, val_loader = synthetic_loaders(n_synth, cfg["MODEL"]["VOXEL_SIZE"])
     else:
         data = datasets.BacchusModule(cfg)
         data.setup()
         train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
+        if world > 1:
+            # every rank LOADS only its own shard (the per-item KD-tree query and the augmentation are the expensive part of
+            # an item): a DistributedSampler over the training set (same number of samples on every rank, reshuffled per
+            # epoch from the epoch number), every W-th item of the validation set
+            from torch.utils.data import DataLoader, Subset
+            from torch.utils.data.distributed import DistributedSampler
+            tds, vds = train_loader.dataset, val_loader.dataset
+            train_sampler = DistributedSampler(tds, num_replicas=world, rank=rank, shuffle=bool(cfg["DATA"]["SHUFFLE"]),
+                                               seed=0, drop_last=True)
+            kw = dict(batch_size=cfg["TRAIN"]["BATCH_SIZE"], collate_fn=data.collate_fn, num_workers=cfg["DATA"]["NUM_WORKER"],
+                      pin_memory=True, drop_last=False, timeout=0)
+            train_loader = DataLoader(tds, sampler=train_sampler, **kw)
+            val_loader = DataLoader(Subset(vds, list(range(rank, len(vds), world))), shuffle=False, **kw)
     model = models.SPSNet(cfg).to(dev)
     (optimizer,), (scheduler,) = model.configure_optimizers()
     epochs = max_epochs if max_epochs is not None else cfg["TRAIN"]["MAX_EPOCH"]
@@ -91,11 +105,14 @@ def main(config, n_synth, max_epochs, out):
     for epoch in range(epochs):
         model.train()
         t0, losses = time.time(), []
-        n_even = len(train_loader) // world * world     # every rank takes the same number of steps (one all-reduce each)
+        sharded = train_sampler is not None
+        if sharded:
+            train_sampler.set_epoch(epoch)
+        n_even = len(train_loader) if sharded else len(train_loader) // world * world     # the same number of steps on every rank
         for i, batch in enumerate(train_loader):
             if i >= n_even:
                 break
-            if i % world != rank:
+            if not sharded and i % world != rank:
                 continue
             optimizer.zero_grad(set_to_none=True)
             out_ = model.training_step(batch.to(dev, non_blocking=True), i)
@@ -104,17 +121,30 @@ def main(config, n_synth, max_epochs, out):
             losses.append(out_["loss"].detach())
         train_loss = float(torch.stack(losses).mean()) if losses else float("nan")
         model.eval()
+        if world > 1:
+            # the parameters are identical on every rank (same initial weights, averaged gradients); the BatchNorm running
+            # statistics are not (every rank saw its own batches): validation and the checkpoint use rank 0's
+            import torch.distributed as dist
+            for buf in model.buffers():
+                dist.broadcast(buf, 0)
+            model.model.mark_weights_dirty()
         vl, vr = [], []
         with torch.no_grad():
             for i, batch in enumerate(val_loader):
                 v = model.validation_step(batch.to(dev, non_blocking=True), i)
                 vl.append(v["val_loss"])
                 vr.append(v["val_r2"])
-        val_loss = float(torch.stack(vl).mean()) if vl else float("nan")
-        val_r2 = float(torch.stack(vr).mean()) if vr else float("nan")
         scheduler.step()
-        if world > 1:                                   # every rank validated the whole split with the same weights
-            import torch.distributed as dist
+        if world > 1 and sharded:                       # every rank validated its own part of the split: pool the sums
+            t = torch.tensor([float(torch.stack(vl).sum()) if vl else 0.0, float(torch.stack(vr).sum()) if vr else 0.0,
+                              float(len(vl))], dtype=torch.float64, device=dev)
+            dist.all_reduce(t)
+            val_loss = float(t[0] / t[2]) if float(t[2]) > 0 else float("nan")
+            val_r2 = float(t[1] / t[2]) if float(t[2]) > 0 else float("nan")
+        else:                                           # (the synthetic lists are validated whole on every rank)
+            val_loss = float(torch.stack(vl).mean()) if vl else float("nan")
+            val_r2 = float(torch.stack(vr).mean()) if vr else float("nan")
+        if world > 1:
             t = torch.tensor([train_loss, float(len(losses))], dtype=torch.float64, device=dev)
             t[0] *= t[1]
             dist.all_reduce(t)

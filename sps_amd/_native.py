@@ -13,6 +13,7 @@ NUM_LEVELS = 5
 SPS_OK = 0
 ERR_RANGE = -4
 ERR_NOMEM = -3
+ERR_INVALID = -1
 
 
 class SpsError(RuntimeError):
@@ -77,9 +78,14 @@ def _load() -> C.CDLL:
         "sps_compact_stable": (i32, [vp, vp, vp, i64, i32, i64, f32, vp, vp, vp]),
         "sps_train_forward": (i32, [vp, vp, i64, vp, i64, i64, f32, vp, vp, vp]),
         "sps_train_backward": (i32, [vp, vp, vp, vp, i64, vp]),
+        "sps_train_generation": (i32, [vp, C.POINTER(i64)]),
+        "sps_train_backward_at": (i32, [vp, i64, vp, vp, vp, i64, vp]),
         "sps_radius_grid_upload": (i32, [vp, vp, vp, vp, vp, i64, i64, C.c_double, C.c_double, vp]),
         "sps_radius_count": (i32, [vp, vp, i64, i64, vp, vp]),
         "sps_radius_fill": (i32, [vp, vp, i64, i64, vp, vp, vp]),
+        "sps_radius_grid_attach": (i32, [vp, vp]),
+        "sps_radius_item": (i32, [vp, vp, i32, i64, i64, f32, vp, vp, i64, i64, vp, vp]),
+        "sps_forward_metrics_n": (i32, [vp, vp, i64, i64, vp, f32, f32, i32, vp, vp, vp]),
         "sps_level_counts": (i32, [vp, C.POINTER(i64)]),
         "sps_get_voxels": (i32, [vp, i32, vp]),
         "sps_get_inverse": (i32, [vp, vp]),
@@ -109,8 +115,8 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_transform_points", "sps_filter_prepare", "sps_forward_n",
-           "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_radius_grid_upload", "sps_radius_count",
-           "sps_radius_fill", "sps_level_counts", "sps_get_voxels",
+           "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_train_generation", "sps_train_backward_at", "sps_radius_grid_upload", "sps_radius_count",
+           "sps_radius_fill", "sps_radius_grid_attach", "sps_radius_item", "sps_forward_metrics_n", "sps_level_counts", "sps_get_voxels",
            "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_logits", "sps_get_feature"]
 
 
@@ -219,6 +225,20 @@ class Context:
                         scores_ptr: int, out_ptr: int, stream: int):
         check(lib.sps_forward_metrics(self.handle, batch_ptr, ld, n, voxel_size, eps, n_batches, scores_ptr, out_ptr, stream))
 
+    def forward_metrics_n(self, batch_ptr: int, ld: int, n_max: int, n_dev_ptr: int, voxel_size: float, eps: float,
+                          n_batches: int, scores_ptr: int, out_ptr: int, stream: int):
+        check(lib.sps_forward_metrics_n(self.handle, batch_ptr, ld, n_max, n_dev_ptr, voxel_size, eps, n_batches, scores_ptr,
+                                        out_ptr, stream))
+
+    def radius_grid_attach(self, owner: "Context"):
+        check(lib.sps_radius_grid_attach(self.handle, owner.handle))
+        self._grid_owner = owner        # the owner keeps the device copies: it must outlive this view
+
+    def radius_item(self, scan_ptr: int, in_f64: bool, ld: int, n: int, batch_index: float, row_off_ptr, rows_ptr: int,
+                    ldo: int, row_cap: int, n_rows_ptr: int, stream: int):
+        check(lib.sps_radius_item(self.handle, scan_ptr, int(in_f64), ld, n, float(batch_index), row_off_ptr, rows_ptr, ldo,
+                                  row_cap, n_rows_ptr, stream))
+
     def forward(self, coords_ptr: int, ld: int, n: int, voxel_size: float, scores_ptr: int, stream: int):
         check(lib.sps_forward(self.handle, coords_ptr, ld, n, voxel_size, scores_ptr, stream))
 
@@ -292,8 +312,18 @@ class Context:
         check(lib.sps_train_forward(self.handle, params_ptr, numel, coords_ptr, ld, n, voxel_size, scores_ptr,
                                     batch_stats_ptr, stream))
 
-    def train_backward(self, dscores_ptr: int, scores_ptr: int, grad_ptr: int, numel: int, stream: int):
-        check(lib.sps_train_backward(self.handle, dscores_ptr, scores_ptr, grad_ptr, numel, stream))
+    def train_backward(self, dscores_ptr: int, scores_ptr: int, grad_ptr: int, numel: int, stream: int, generation=None):
+        """``generation`` (train_generation() right after the forward): refuse to differentiate a forward whose activations
+        a later forward on this context has overwritten."""
+        if generation is None:
+            check(lib.sps_train_backward(self.handle, dscores_ptr, scores_ptr, grad_ptr, numel, stream))
+        else:
+            check(lib.sps_train_backward_at(self.handle, int(generation), dscores_ptr, scores_ptr, grad_ptr, numel, stream))
+
+    def train_generation(self) -> int:
+        g = C.c_int64()
+        check(lib.sps_train_generation(self.handle, C.byref(g)))
+        return g.value
 
     def level_counts(self):
         out = (C.c_int64 * NUM_LEVELS)()

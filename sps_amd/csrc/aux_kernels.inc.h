@@ -378,35 +378,134 @@ __global__ void k_radius_cells_insert(const unsigned long long *__restrict__ cel
 }
 
 // One thread per (scan point i, neighbour cell c in 0..26; c = (dx+1) + 3(dy+1) + 9(dz+1)).
-// MODE 0: counts[i*27 + c] = hits of point i in that cell.  MODE 1: write them at offsets[i*27 + c].
-// A point's list is therefore ordered by cell, ascending map index inside a cell.
-template <int MODE>
-__global__ void k_radius_query(const double *__restrict__ scan, int64_t ld, int n, RadiusGrid g,
+// MODE 0: counts[i*27 + c] = hits of point i in that cell.  MODE 1: write their map indices at offsets[i*27 + c].
+// MODE 2: write them as item rows (b, x, y, z, t = 0, label = 1) of the map points (blt_dataset.py:227-233) at row
+//         row_base + offsets32[i*27 + c], rows beyond row_cap dropped.
+// A point's list is therefore ordered by cell, ascending map index inside a cell.  TIN = the scan's dtype (float rows
+// are promoted to float64, as cKDTree does with a float32 array).
+struct ItemOut {
+  float *rows;           // [row_cap, ld]
+  int64_t ld;
+  int row_cap;
+  const int *row_base;   // device: first row of this item's submap part
+  float b;
+};
+template <typename TIN, int MODE>
+__global__ void k_radius_query(const TIN *__restrict__ scan, int64_t ld, int n, RadiusGrid g,
                                int *__restrict__ counts, const int64_t *__restrict__ offsets,
-                               int64_t *__restrict__ out) {
+                               int64_t *__restrict__ out, const int *__restrict__ offsets32, ItemOut io) {
   const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (tid >= (int64_t)n * 27) return;
   const int i = (int)(tid / 27), c27 = (int)(tid - (int64_t)i * 27);
-  const double px = scan[(size_t)i * ld], py = scan[(size_t)i * ld + 1], pz = scan[(size_t)i * ld + 2];
+  const double px = (double)scan[(size_t)i * ld], py = (double)scan[(size_t)i * ld + 1], pz = (double)scan[(size_t)i * ld + 2];
   long long cx, cy, cz;
   int cnt = 0;
   int64_t *dst = MODE == 1 ? out + offsets[tid] : nullptr;
+  const int rb = MODE == 2 ? *io.row_base + offsets32[tid] : 0;
   if (radius_cell(px, g.inv_cell, cx) && radius_cell(py, g.inv_cell, cy) && radius_cell(pz, g.inv_cell, cz)) {
     const int s = hash_find_slot(g.h, radius_key(cx + (c27 % 3 - 1), cy + ((c27 / 3) % 3 - 1), cz + (c27 / 9 - 1)));
     if (s >= 0) {
       const int c = g.h.rank[s];
       for (int t = g.cell_start[c]; t < g.cell_start[c + 1]; ++t) {
         const int j = g.cell_pts[t];
-        const double ex = px - g.xyz[(size_t)j * 3], ey = py - g.xyz[(size_t)j * 3 + 1], ez = pz - g.xyz[(size_t)j * 3 + 2];
+        const double mx = g.xyz[(size_t)j * 3], my = g.xyz[(size_t)j * 3 + 1], mz = g.xyz[(size_t)j * 3 + 2];
+        const double ex = px - mx, ey = py - my, ez = pz - mz;
         const double d2 = __dadd_rn(__dadd_rn(__dmul_rn(ex, ex), __dmul_rn(ey, ey)), __dmul_rn(ez, ez));
         if (d2 <= g.r2) {
           if (MODE == 1) dst[cnt] = j;
+          if (MODE == 2 && rb + cnt < io.row_cap) {
+            float *o = io.rows + (size_t)(rb + cnt) * io.ld;
+            o[0] = io.b, o[1] = (float)mx, o[2] = (float)my, o[3] = (float)mz, o[4] = 0.f, o[5] = 1.f;
+          }
           ++cnt;
         }
       }
     }
   }
   if (MODE == 0) counts[tid] = cnt;
+}
+
+// ---- exclusive prefix sum of int32 counts in three stream-ordered launches (no host round trip) -----------------
+// k_scan_partial: sums of 4096-element blocks; k_scan_top: one workgroup turns them into exclusive block offsets and
+// publishes the item's row counts; k_scan_apply: out[i] = block offset + exclusive prefix inside the block.
+constexpr int PSCAN_PER_THREAD = 16, PSCAN_BLOCK = 256 * PSCAN_PER_THREAD;
+__device__ inline int pscan_block_exclusive(int v, int *sh /*[4]*/, int &block_total) {  // exclusive scan over the 256 threads
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int x = v;
+  for (int o = 1; o < 64; o <<= 1) {
+    const int y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) sh[wave] = x;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wave; ++w) base += sh[w];
+  block_total = sh[0] + sh[1] + sh[2] + sh[3];
+  return base + x - v;
+}
+__global__ __launch_bounds__(256) void k_scan_partial(const int *__restrict__ in, int64_t n, int *__restrict__ bsum) {
+  __shared__ int sh[4];
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PSCAN_PER_THREAD;
+  int v = 0;
+  for (int j = 0; j < PSCAN_PER_THREAD; ++j) v += i0 + j < n ? in[i0 + j] : 0;
+  int tot;
+  (void)pscan_block_exclusive(v, sh, tot);
+  if (threadIdx.x == 0) bsum[blockIdx.x] = tot;
+}
+// item bookkeeping done by the same single workgroup: n_rows_out = row offset of the item + scan rows + submap rows
+// (clamped to the buffer; overflow sets error bit 2 = item buffer too small), sub_base = first submap row
+__global__ __launch_bounds__(256) void k_scan_top(int *__restrict__ bsum, int nb, const int *__restrict__ row_off, int n_scan,
+                                                   int row_cap, int *__restrict__ sub_base, int *__restrict__ n_rows_out,
+                                                   int *__restrict__ err) {
+  __shared__ int sh[4];
+  int carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 256) {
+    const int i = b0 + (int)threadIdx.x;
+    const int v = i < nb ? bsum[i] : 0;
+    int tot;
+    const int ex = pscan_block_exclusive(v, sh, tot);
+    if (i < nb) bsum[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int r0 = row_off ? *row_off : 0;
+    *sub_base = r0 + n_scan;
+    long long total = (long long)r0 + n_scan + carry;
+    if (total > row_cap) {
+      atomicOr(err, 4);
+      total = row_cap;
+    }
+    *n_rows_out = (int)total;
+  }
+}
+__global__ __launch_bounds__(256) void k_scan_apply(const int *__restrict__ in, int64_t n, const int *__restrict__ bsum,
+                                                     int *__restrict__ out) {
+  __shared__ int sh[4];
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * PSCAN_PER_THREAD;
+  int loc[PSCAN_PER_THREAD];
+  int v = 0;
+  for (int j = 0; j < PSCAN_PER_THREAD; ++j) {
+    loc[j] = i0 + j < n ? in[i0 + j] : 0;
+    v += loc[j];
+  }
+  int tot;
+  int run = bsum[blockIdx.x] + pscan_block_exclusive(v, sh, tot);
+  for (int j = 0; j < PSCAN_PER_THREAD; ++j) {
+    if (i0 + j < n) out[i0 + j] = run;
+    run += loc[j];
+  }
+}
+// scan part of an item (blt_dataset.py:213-221): rows (b, x, y, z, t = 1, label) as float32
+template <typename TIN>
+__global__ void k_item_scan_rows(const TIN *__restrict__ scan, int64_t ld, int n, const int *__restrict__ row_off, ItemOut io) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = (row_off ? *row_off : 0) + i;
+  if (r >= io.row_cap) return;
+  const TIN *p = scan + (size_t)i * ld;
+  float *o = io.rows + (size_t)r * io.ld;
+  o[0] = io.b, o[1] = (float)p[0], o[2] = (float)p[1], o[3] = (float)p[2], o[4] = 1.f, o[5] = (float)p[3];
 }
 
 // ------------------------------------------------------------------------------------------

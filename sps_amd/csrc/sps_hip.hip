@@ -23,8 +23,9 @@
 //   kernel map  : output-stationary neighbour table nbr[k][row] (k-major, -1 = absent) + a 128-bit
 //                 present-offset mask per 16-row tile
 //   features    : row-major f32 [V, C]; concatenations are strided views of one buffer (ME.cat costs nothing)
-// Diagnostic environment hooks (never needed in product use): SPS_GEOM_L<l>, SPS_CONV_MAX_WG,
-// SPS_DIAG_SKIP, SPS_NO_MERGE, SPS_GRID_SCALE; compile-time SPS_ABLATE_* (private builds: tools/variant_sweep.sh).
+// The product build reads NO environment variable and carries no diagnostic switch.  Private diagnostic builds
+// (tools/*_sweep.sh: hipcc -DSPS_DIAG ..., loaded through $SPS_LIB) add the hooks diag_env() reads (SPS_GEOM_L<l>,
+// SPS_CONV_MAX_WG, SPS_DIAG_SKIP, SPS_NO_MERGE, SPS_GRID_SCALE, SPS_PX) and the compile-time SPS_ABLATE_* / SPS_WAVE_TRACE blocks.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -41,12 +42,29 @@
 
 #include "../../include/sps_hip.h"
 
+#if !defined(SPS_DIAG)  // the ablation / trace blocks exist in -DSPS_DIAG builds only
+#undef SPS_ABLATE_A
+#undef SPS_ABLATE_B
+#undef SPS_ABLATE_MFMA
+#undef SPS_ABLATE_LOOP
+#undef SPS_ABLATE_STAGE
+#undef SPS_ABLATE_C0FETCH
+#undef SPS_WAVE_TRACE
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
 // errors
 // ------------------------------------------------------------------------------------------
 thread_local std::string g_err;
+
+// diagnostic environment hooks: compiled into -DSPS_DIAG builds only (the product library never calls getenv)
+#if defined(SPS_DIAG)
+inline const char *diag_env(const char *name) { return getenv(name); }
+#else
+inline const char *diag_env(const char *) { return nullptr; }
+#endif
 
 int fail(int code, const char *fmt, ...) {
   char buf[512];
@@ -178,11 +196,15 @@ struct sps_weights {
   float final_bias = 0.f;
   const NetSpec *net = nullptr;
   ~sps_weights() {
+    // runs from the host language's GC at an arbitrary point: the caller's current device is left as it was
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     (void)hipSetDevice(device);
     (void)hipDeviceSynchronize();  // forwards in flight may still read them
     (void)hipFree(blob);
     (void)hipFree(ss);
     (void)hipFree(wu);
+    if (prev >= 0 && prev != device) (void)hipSetDevice(prev);
   }
 };
 struct sps_weights_handle {  // what the C ABI hands out: one reference
@@ -209,6 +231,7 @@ struct sps_ctx {
   bool lean = false;
   uint64_t arena_gen = 0;  // bumped by every (re)allocation of the arena: dependants (training views) re-derive their pointers
   int64_t last_n = 0;    // points of the last forward
+  uint64_t fwd_gen = 0;  // bumped by every forward: what the activations / maps held by the context belong to
   bool have_weights = false;
   std::vector<void *> allocs;
   Level lv[SPS_NUM_LEVELS];
@@ -244,6 +267,11 @@ struct sps_ctx {
   float *x2 = nullptr, *b2t = nullptr, *cat6 = nullptr, *b6t = nullptr, *b6o = nullptr;
   float *x3 = nullptr, *b3t = nullptr, *cat5 = nullptr, *b5t = nullptr, *b5o = nullptr;
   float *x4 = nullptr, *b4t = nullptr, *b4o = nullptr;
+  // k_conv_ws (levels 2-4): partial sums of the offset slices + one ticket per supertile (self-resetting)
+  float *ws_slab = nullptr;
+  int *ws_ticket = nullptr;
+  size_t ws_slab_bytes = 0;
+  int64_t ws_tickets = 0;
   // per-stage hipEvent profiling (sps_profile_*): off by default
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -252,6 +280,9 @@ struct sps_ctx {
   // variant-A radius grid (device copies owned by the ctx)
   RadiusGrid rg{};
   std::vector<void *> rg_allocs;
+  // variant-A item scratch (sps_radius_item): per (scan point, neighbour cell) hit counts and their prefix sums
+  int *item_counts = nullptr, *item_offsets = nullptr, *item_bsum = nullptr, *item_base = nullptr;
+  int64_t item_cap = 0;
   // map hash (variant-B submap)
   HashTable map{};
   int64_t map_cap = 0;
@@ -264,7 +295,7 @@ namespace {
 // levels whose one-column-tile 3x3x3x3 layers run pair-exact (k_rulebook + k_conv_px).  SPS_PX = bit mask (DIAGNOSTICS:
 // A/B against k_conv; read once)
 int px_levels() {
-  static const int m = [] { const char *e = getenv("SPS_PX"); return (e ? atoi(e) : SPS_PX_DEFAULT) & ((1 << PX_LEVELS) - 1); }();
+  static const int m = [] { const char *e = diag_env("SPS_PX"); return (e ? atoi(e) : SPS_PX_DEFAULT) & ((1 << PX_LEVELS) - 1); }();
   return m;
 }
 
@@ -431,6 +462,20 @@ int reserve(sps_ctx *c, int64_t n) {
   ALLOC(c->x4, float, 32 * cl[4]);
   ALLOC(c->b4t, float, 64 * cl[4]);
   ALLOC(c->b4o, float, 64 * cl[4]);
+#if defined(SPS_DIAG)  // k_conv_ws (experimental coarse-level kernel): slab + tickets
+  {
+    // a launch cuts its supertiles' offset lists into S = clamp(WS_TARGET / supertiles, 2, WS_SMAX) slices: at most
+    // max(2 * supertiles, WS_TARGET) work items of 4 waves x <= 4 column tiles x 1 KB
+    int64_t items = WS_TARGET;
+    for (int l = WS_FIRST_LEVEL; l < SPS_NUM_LEVELS; ++l) items = std::max<int64_t>(items, 2 * (cl[l] / 64));
+    c->ws_slab_bytes = (size_t)items * 16384;
+    if (c->ws_slab_bytes > 0xFFFF0000ull) return fail(SPS_ERR_NOMEM, "k_conv_ws slab exceeds a buffer descriptor");
+    ALLOC(c->ws_slab, float, c->ws_slab_bytes / 4);
+    c->ws_tickets = cl[std::min(WS_FIRST_LEVEL, SPS_NUM_LEVELS - 1)] / 64;
+    ALLOC(c->ws_ticket, int, c->ws_tickets);
+    HIP_TRY(hipMemset(c->ws_ticket, 0, sizeof(int) * (size_t)c->ws_tickets));
+  }
+#endif
   c->cap = cap;
   c->hcap = hcap;
   c->last_n = 0;
@@ -519,6 +564,7 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   // (serial 0.552 -> 0.506 ms) and two column tiles per wave halve the re-gathers of A (pipelined +2.7 % per level
   // group over one column tile per wave, tools/geom_sweep.sh)
   Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{std::min(2, nt), 4};
+#if defined(SPS_DIAG)
   // tuning hook (diagnostics): SPS_GEOM_L<level>="<ntw>,<S>"  column tiles per wave (1, 2, 4; clipped to NT) and splits
   // of the unit list inside the workgroup (1, 2, 4); read once
   struct Hook {
@@ -530,7 +576,7 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
     for (int l = 0; l < SPS_NUM_LEVELS; ++l) {
       char name[32];
       snprintf(name, sizeof name, "SPS_GEOM_L%d", l);
-      const char *e = getenv(name);
+      const char *e = diag_env(name);
       int ntw = 1, S = 1;
       if (e && sscanf(e, "%d,%d", &ntw, &S) == 2 && (S == 1 || S == 2 || S == 4) && (ntw == 1 || ntw == 2 || ntw == 4))
         h[l] = Hook{true, ntw, S};
@@ -538,6 +584,7 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
     return h;
   }();
   if (level >= 0 && level < SPS_NUM_LEVELS && hooks[level].set) g = {std::min(hooks[level].ntw, nt), hooks[level].S};
+#endif
   return g;
 }
 
@@ -607,10 +654,10 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   if (gx < 64) gx = 64;
   if (gx > 4096) gx = 4096;
   {
-    static const float gscale = [] { const char *e = getenv("SPS_GRID_SCALE"); return e ? (float)atof(e) : 1.f; }();  // DIAGNOSTICS
+    static const float gscale = [] { const char *e = diag_env("SPS_GRID_SCALE"); return e ? (float)atof(e) : 1.f; }();  // DIAGNOSTICS
     if (gscale != 1.f) gx = std::max<int64_t>(16, (int64_t)((float)gx * gscale));
   }
-  static const int max_wg = [] { const char *e = getenv("SPS_CONV_MAX_WG"); return e ? atoi(e) : 0; }();
+  static const int max_wg = [] { const char *e = diag_env("SPS_CONV_MAX_WG"); return e ? atoi(e) : 0; }();
   if (max_wg > 0 && gx * (a.NT / g.ntw) * g.S > max_wg) gx = std::max<int64_t>(16, max_wg / ((a.NT / g.ntw) * g.S));
   // a workgroup holds 4 / S tiles x S splits: S times as many workgroups for the same tiles
   const dim3 grid((unsigned)(a.NT / g.ntw), (unsigned)(gx * g.S), 1u);  // x = column group (fastest), y = tile group
@@ -633,7 +680,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->capl[cc.level_out] * 4u);
   a.tile_cap = (int)(c->capl[cc.level_out] / 16);
   {
-    static const char *trace_layer = getenv("SPS_TRACE_LAYER");  // diagnostic builds (-DSPS_WAVE_TRACE) only
+    static const char *trace_layer = diag_env("SPS_TRACE_LAYER");  // diagnostic builds (-DSPS_WAVE_TRACE) only
     a.trace_on = trace_layer && std::strcmp(trace_layer, cc.name) == 0;
   }
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
@@ -702,6 +749,32 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
 #undef SPS_PX_LAUNCH
     return SPS_OK;
   }
+#if defined(SPS_DIAG)
+  // wide 3x3x3x3 layers of the coarse levels: weight-sharing kernel (weights of a stage in LDS, offsets sliced over workgroups)
+  if (cs.K == 81 && cc.level_out >= WS_FIRST_LEVEL && a.NT >= 2 && a.nbr && !cc.fin && cs.cin % 16 == 0 && cs.ds_cin % 16 == 0) {
+    a.slab = c->ws_slab;
+    a.ticket = c->ws_ticket;
+    a.slab_bytes = (uint32_t)c->ws_slab_bytes;
+    a.ws_target = WS_TARGET;
+    a.ws_smax = WS_SMAX;
+    if (c->capl[cc.level_out] / 64 > c->ws_tickets) return fail(SPS_ERR_INVALID, "k_conv_ws: ticket array too small");
+    const dim3 gridw((unsigned)std::min<int64_t>(1024, std::max<int64_t>(WS_TARGET, 2 * (((c->cap / 64) >> cc.level_out) + 1))));
+    const int key = cs.cin * 1000 + a.NT * 100 + cs.ds_cin;
+#define SPS_WS_LAUNCH(CIN_, NT_, DS_) hipLaunchKernelGGL((k_conv_ws<CIN_, NT_, DS_>), gridw, dim3(256), 0, st, a)
+    switch (key) {
+      case 16200: SPS_WS_LAUNCH(16, 2, 0); return SPS_OK;    // block3.conv1
+      case 32216: SPS_WS_LAUNCH(32, 2, 16); return SPS_OK;   // block3.conv2
+      case 32400: SPS_WS_LAUNCH(32, 4, 0); return SPS_OK;    // block4.conv1
+      case 64432: SPS_WS_LAUNCH(64, 4, 32); return SPS_OK;   // block4.conv2
+      case 96400: SPS_WS_LAUNCH(96, 4, 0); return SPS_OK;    // block5.conv1
+      case 64496: SPS_WS_LAUNCH(64, 4, 96); return SPS_OK;   // block5.conv2
+      case 48200: SPS_WS_LAUNCH(48, 2, 0); return SPS_OK;    // block6.conv1
+      case 32248: SPS_WS_LAUNCH(32, 2, 48); return SPS_OK;   // block6.conv2
+      default: break;                                         // any other shape: k_conv
+    }
+#undef SPS_WS_LAUNCH
+  }
+#endif
   if (cs.K == 81 && !a.nbr)
     return fail(SPS_ERR_INVALID, "%s has no pair-exact instantiation and the inference-only context keeps no neighbour table at level %d",
                 cc.name, cc.level_out);
@@ -759,6 +832,25 @@ std::vector<Feat> feature_taps(sps_ctx *c) {
 }
 
 template <typename TIN>
+int radius_item_launch(sps_ctx *c, const TIN *scan, int64_t ld, int64_t n, const int32_t *row_off_dev, ItemOut io,
+                              int32_t *n_rows_dev, hipStream_t st) {
+  const int64_t n27 = n * 27;
+  const int nb = (int)((n27 + PSCAN_BLOCK - 1) / PSCAN_BLOCK);
+  const unsigned gq = (unsigned)((n27 + 255) / 256);
+  hipLaunchKernelGGL((k_item_scan_rows<TIN>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, scan, ld, (int)n, row_off_dev, io);
+  hipLaunchKernelGGL((k_radius_query<TIN, 0>), dim3(gq), dim3(256), 0, st, scan, ld, (int)n, c->rg, c->item_counts, nullptr,
+                     nullptr, nullptr, ItemOut{});
+  hipLaunchKernelGGL(k_scan_partial, dim3((unsigned)nb), dim3(256), 0, st, c->item_counts, n27, c->item_bsum);
+  hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, c->item_bsum, nb, row_off_dev, (int)n, io.row_cap, c->item_base,
+                     n_rows_dev, c->err);
+  hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nb), dim3(256), 0, st, c->item_counts, n27, c->item_bsum, c->item_offsets);
+  io.row_base = c->item_base;
+  hipLaunchKernelGGL((k_radius_query<TIN, 2>), dim3(gq), dim3(256), 0, st, scan, ld, (int)n, c->rg, nullptr, nullptr, nullptr,
+                     c->item_offsets, io);
+  return SPS_OK;
+}
+
+template <typename TIN>
 int transform_launch(const TIN *in, int64_t ld, int64_t n, const Mat4 &T, int identity, void *out, int out_f64,
                             bool with_bt, int64_t ldo, hipStream_t st) {
   const dim3 g((unsigned)((n + 255) / 256)), b(256);
@@ -812,6 +904,7 @@ int sps_ctx_destroy(sps_ctx *c) {
   c->weights.reset();
   if (c->map_keys_alloc) (void)hipFree(c->map_keys_alloc);
   for (void *p : c->rg_allocs) (void)hipFree(p);
+  for (void *p : {(void *)c->item_counts, (void *)c->item_offsets, (void *)c->item_bsum, (void *)c->item_base}) (void)hipFree(p);
   delete c;
   return SPS_OK;
 }
@@ -1041,6 +1134,25 @@ int sps_forward_metrics(sps_ctx *c, const float *batch, int64_t ld, int64_t n, f
   return forward_impl(c, batch, ld, n, vs, scores, fo, stream);
 }
 
+int sps_forward_metrics_n(sps_ctx *c, const float *batch, int64_t ld, int64_t n_max, const int32_t *n_dev, float vs, float eps,
+                          int n_batches, float *scores, double *out_dev, void *stream) {
+  if (c && c->have_weights && c->net->out_channels != 1)
+    return fail(SPS_ERR_INVALID, "the loaded weights have a %d-channel head: use sps_forward_head", c->net->out_channels);
+  if (!out_dev || !n_dev) return fail(SPS_ERR_INVALID, "null argument");
+  if (n_batches < 1 || n_batches > 31) return fail(SPS_ERR_INVALID, "n_batches must be in [1,31]");
+  if (ld < 6) return fail(SPS_ERR_INVALID, "rows must carry (b,x,y,z,t,label): ld >= 6");
+  if (n_max == 0) {
+    HIP_TRY(hipSetDevice(c ? c->device : 0));
+    HIP_TRY(hipMemsetAsync(out_dev, 0, (size_t)n_batches * 8 * sizeof(double), (hipStream_t)stream));
+  }
+  ForwardOpts fo;
+  fo.metrics_out = out_dev;
+  fo.eps = eps;
+  fo.n_batches = n_batches;
+  fo.n_dev = n_dev;
+  return forward_impl(c, batch, ld, n_max, vs, scores, fo, stream);
+}
+
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
                         const ForwardOpts &fo, void *stream) {
   if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
@@ -1056,20 +1168,21 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   }
   // DIAGNOSTICS ONLY: SPS_DIAG_SKIP bit 0 = reuse the coordinate structures of the
   // previous forward (valid for an identical input), bit 1 = skip the convolutions.  Never set in product use.
-  static const int diag_skip = [] { const char *e = getenv("SPS_DIAG_SKIP"); return e ? atoi(e) : 0; }();
+  static const int diag_skip = [] { const char *e = diag_env("SPS_DIAG_SKIP"); return e ? atoi(e) : 0; }();
   // DIAGNOSTICS: SPS_NO_MERGE bit i launches the parts of merged kernel i separately (0 rows|ancestors,
   // 1 link|adj, 2 nbr3|stride maps, 3 slice|cleanup)
-  static const int no_merge = [] { const char *e = getenv("SPS_NO_MERGE"); return e ? atoi(e) : 0; }();
+  static const int no_merge = [] { const char *e = diag_env("SPS_NO_MERGE"); return e ? atoi(e) : 0; }();
   const bool skip_front = (diag_skip & 1) && c->last_n == n && c->diag_have_state;
   const bool skip_convs = (diag_skip & 2) != 0;
   c->last_n = n;
+  ++c->fwd_gen;  // whatever an earlier forward left in the context (training activations, kernel maps) is gone
   const int64_t cap = c->cap;
   c->prof_n = 0;
   prof_mark(c, "begin", st);
   Level &L0 = c->lv[0];
   PyramidArgs pa = pyramid_args(c);
   pa.n_dev = fo.n_dev;
-  if (fo.n_dev && (fo.head || fo.feats || fo.metrics_out)) return fail(SPS_ERR_INVALID, "a device-side row count is only supported by sps_forward_n");
+  if (fo.n_dev && (fo.head || fo.feats)) return fail(SPS_ERR_INVALID, "a device-side row count is only supported by sps_forward_n / sps_forward_metrics_n");
   if (!skip_front) {
   // ---- reset: the block hashes are cleaned by the previous forward; full reset only when dirty
   if (c->tables_dirty) {
@@ -1277,6 +1390,12 @@ static int report_device_errors(sps_ctx *c, int e, hipStream_t st) {
                                "sps_ctx_set_level_fractions): the forward was aborted and its scores are NaN; the context "
                                "has switched to full-size arenas, re-issue the forward");
   }
+  if (e & 8)
+    return fail(SPS_ERR_INVALID, "train-mode BatchNorm: a level of the training forward had a single active row (Expected more "
+                                 "than 1 value per channel when training)");
+  if (e & 4)
+    return fail(SPS_ERR_NOMEM, "sps_radius_item: the item buffer is too small for the scan rows + the radius submap rows "
+                               "(the rows beyond it were dropped): pass a larger row_cap");
   return fail(SPS_ERR_RANGE,
               "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");
 }
@@ -1576,8 +1695,8 @@ int sps_radius_count(sps_ctx *c, const double *scan_xyz_dev, int64_t ld, int64_t
   if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points");
   HIP_TRY(hipSetDevice(c->device));
   if (n > 0)
-    hipLaunchKernelGGL(k_radius_query<0>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       scan_xyz_dev, ld, (int)n, c->rg, counts_dev, nullptr, nullptr);
+    hipLaunchKernelGGL((k_radius_query<double, 0>), dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       scan_xyz_dev, ld, (int)n, c->rg, counts_dev, nullptr, nullptr, nullptr, ItemOut{});
   HIP_TRY(hipGetLastError());
   return SPS_OK;
 }
@@ -1589,8 +1708,56 @@ int sps_radius_fill(sps_ctx *c, const double *scan_xyz_dev, int64_t ld, int64_t 
   if (n > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points");
   HIP_TRY(hipSetDevice(c->device));
   if (n > 0)
-    hipLaunchKernelGGL(k_radius_query<1>, dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       scan_xyz_dev, ld, (int)n, c->rg, nullptr, offsets_dev, out_idx_dev);
+    hipLaunchKernelGGL((k_radius_query<double, 1>), dim3((unsigned)((n * 27 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       scan_xyz_dev, ld, (int)n, c->rg, nullptr, offsets_dev, out_idx_dev, nullptr, ItemOut{});
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_radius_grid_attach(sps_ctx *c, sps_ctx *owner) {
+  if (!c || !owner) return fail(SPS_ERR_INVALID, "null argument");
+  if (c == owner) return SPS_OK;
+  if (c->device != owner->device) return fail(SPS_ERR_INVALID, "the contexts live on different devices");
+  if (!owner->rg.h.keys) return fail(SPS_ERR_INVALID, "sps_radius_grid_upload has not been called on the owner");
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->rg_allocs.empty()) {
+    HIP_TRY(hipDeviceSynchronize());
+    for (void *p : c->rg_allocs) (void)hipFree(p);
+    c->rg_allocs.clear();
+  }
+  c->rg = owner->rg;  // a view: the owner keeps (and frees) the allocations
+  return SPS_OK;
+}
+
+int sps_radius_item(sps_ctx *c, const void *scan_dev, int in_f64, int64_t ld, int64_t n, float batch_index,
+                    const int32_t *row_off_dev, float *rows_dev, int64_t ldo, int64_t row_cap, int32_t *n_rows_dev, void *stream) {
+  if (!c || n < 0 || ld < 4 || ldo < 6 || row_cap < 0 || !n_rows_dev || (row_cap > 0 && !rows_dev) || (n > 0 && !scan_dev))
+    return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!c->rg.h.keys) return fail(SPS_ERR_INVALID, "sps_radius_grid_upload has not been called");
+  if (n > SPS_MAX_POINTS || row_cap > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points");
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (n > c->item_cap) {  // scratch of the scans: grows once per context (first use / a larger scan)
+    HIP_TRY(hipDeviceSynchronize());
+    for (void *p : {(void *)c->item_counts, (void *)c->item_offsets, (void *)c->item_bsum, (void *)c->item_base}) (void)hipFree(p);
+    c->item_counts = c->item_offsets = c->item_bsum = c->item_base = nullptr;
+    c->item_cap = 0;
+    const int64_t cap = ((n + n / 4 + 1023) / 1024) * 1024;
+    const size_t n27 = (size_t)cap * 27;
+    if (hipMalloc((void **)&c->item_counts, n27 * 4) != hipSuccess || hipMalloc((void **)&c->item_offsets, n27 * 4) != hipSuccess ||
+        hipMalloc((void **)&c->item_bsum, ((n27 + PSCAN_BLOCK - 1) / PSCAN_BLOCK + 1) * 4) != hipSuccess ||
+        hipMalloc((void **)&c->item_base, 16) != hipSuccess)
+      return fail(SPS_ERR_NOMEM, "hipMalloc for the item scratch failed");
+    c->item_cap = cap;
+  }
+  ItemOut io{rows_dev, ldo, (int)row_cap, nullptr, batch_index};
+  if (n == 0) {
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, st, c->item_bsum, 0, row_off_dev, 0, io.row_cap, c->item_base, n_rows_dev, c->err);
+  } else if (in_f64) {
+    radius_item_launch(c, (const double *)scan_dev, ld, n, row_off_dev, io, n_rows_dev, st);
+  } else {
+    radius_item_launch(c, (const float *)scan_dev, ld, n, row_off_dev, io, n_rows_dev, st);
+  }
   HIP_TRY(hipGetLastError());
   return SPS_OK;
 }

@@ -59,6 +59,7 @@ struct sps_train {
   std::vector<TView> views;
   int64_t n_last = 0;
   bool have_forward = false;
+  uint64_t fwd_gen = 0;  // c->fwd_gen of the forward whose activations are held
 };
 
 namespace {
@@ -412,6 +413,7 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
   if (rc != SPS_OK) return rc;
   sps_train *t = c->train;
   t->have_forward = false;
+  hipLaunchKernelGGL(k_train_check_rows, dim3(1), dim3(64), 0, st, c->counts, c->err);
   HIP_TRY(hipMemcpyAsync(t->blob, params_dev, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
   // operands of this step's weights
   hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)t->perm_blocks), dim3(256), 0, st, t->perm, t->n_perm, t->blob, t->wu, t->wut);
@@ -458,10 +460,38 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
   HIP_TRY(hipGetLastError());
   t->n_last = n;
   t->have_forward = true;
+  t->fwd_gen = c->fwd_gen;
   return SPS_OK;
 }
 
+int sps_train_generation(sps_ctx *c, int64_t *generation) {
+  if (!c || !generation) return fail(SPS_ERR_INVALID, "null argument");
+  if (!c->train || !c->train->have_forward) return fail(SPS_ERR_INVALID, "sps_train_forward has not been called on this context");
+  *generation = (int64_t)c->train->fwd_gen;
+  return SPS_OK;
+}
+
+static int train_backward_impl(sps_ctx *c, const float *dscores, const float *scores, float *grad_dev, int64_t numel, void *stream);
+
+int sps_train_backward_at(sps_ctx *c, int64_t generation, const float *dscores, const float *scores, float *grad_dev, int64_t numel,
+                          void *stream) {
+  if (!c) return fail(SPS_ERR_INVALID, "null argument");
+  sps_train *t = c->train;
+  if (!t || !t->have_forward) return fail(SPS_ERR_INVALID, "sps_train_forward has not been called on this context");
+  if ((uint64_t)generation != t->fwd_gen || c->fwd_gen != t->fwd_gen)
+    return fail(SPS_ERR_INVALID, "the activations of that training forward (generation %lld) were overwritten by a later forward on "
+                                 "this context (now at %llu): run forward and backward of a step back to back, or use one context "
+                                 "per live autograd graph", (long long)generation, (unsigned long long)c->fwd_gen);
+  return train_backward_impl(c, dscores, scores, grad_dev, numel, stream);
+}
+
 int sps_train_backward(sps_ctx *c, const float *dscores, const float *scores, float *grad_dev, int64_t numel, void *stream) {
+  if (!c) return fail(SPS_ERR_INVALID, "null argument");
+  if (!c->train || !c->train->have_forward) return fail(SPS_ERR_INVALID, "sps_train_forward has not been called on this context");
+  return sps_train_backward_at(c, (int64_t)c->train->fwd_gen, dscores, scores, grad_dev, numel, stream);
+}
+
+static int train_backward_impl(sps_ctx *c, const float *dscores, const float *scores, float *grad_dev, int64_t numel, void *stream) {
   if (!c || !dscores || !scores || !grad_dev) return fail(SPS_ERR_INVALID, "null argument");
   sps_train *t = c->train;
   if (!t || !t->have_forward) return fail(SPS_ERR_INVALID, "sps_train_forward has not been called on this context");

@@ -528,3 +528,9 @@ __global__ void k_final_bwd_reduce(const double *__restrict__ part, float *__res
   if (j < 8) dw[j] = (float)s;
   else db[0] = (float)s;
 }
+
+// nn.BatchNorm1d in training mode refuses a single value per channel (the reference's MinkowskiBatchNorm raises): a level
+// with exactly one active row sets error bit 3 (reported by the next synchronising call)
+__global__ void k_train_check_rows(const int *__restrict__ counts, int *__restrict__ err) {
+  if (threadIdx.x < NLV && counts[threadIdx.x] == 1) atomicOr(err, 8);
+}

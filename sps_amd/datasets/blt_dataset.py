@@ -150,7 +150,7 @@ class DeviceRadiusSubmap:
     kept; inside one scan point's list the hits are ordered by neighbour cell, ascending map index inside a
     cell (scipy's order there is the KD-tree's traversal order, i.e. unspecified)."""
 
-    def __init__(self, map_xyz, radius: float, device="cuda"):
+    def __init__(self, map_xyz, radius: float, device="cuda", ctx=None):
         from ..models import models
         self.radius = float(radius)
         self.device = torch.device(device)
@@ -166,7 +166,8 @@ class DeviceRadiusSubmap:
         pts = order.to(torch.int32).contiguous()
         with torch.cuda.device(self.device):
             self.stream = torch.cuda.current_stream().cuda_stream
-            self.ctx = models.get_context(self.device.index or 0, self.stream)
+            # the context that owns the grid's device copies (others attach to it: Context.radius_grid_attach)
+            self.ctx = ctx if ctx is not None else models.get_context(self.device.index or 0, self.stream)
             from .. import _native
             _native.check(_native.lib.sps_radius_grid_upload(
                 self.ctx.handle, ukeys.contiguous().data_ptr(), start.data_ptr(), pts.data_ptr(), xyz.data_ptr(),

@@ -49,8 +49,23 @@ class ScanEngine:
         for cx in self.ctxs:
             cx.set_inference_only(True)
         self._next = 0
-        self._stage = [None] * S          # per-stream device staging buffer for host batches
-        self._pinned = [None] * S
+        self._stage = [None] * S          # per-stream PAIR of device staging buffers for host batches
+        self._pinned = [None] * S         # (pageable host batches only: pinned bounce buffers)
+        self._flip = [0] * S
+        self._stage_free = [[None, None] for _ in range(S)]   # event: the forward that read the buffer was issued ... and done
+        self._copied = [[None, None] for _ in range(S)]       # event: the copy into the buffer is done
+        self._pending_slot = None
+        with torch.cuda.device(self.device):
+            self.copy_stream = torch.cuda.Stream(device=self.device)
+        # device item path (attach_map / submit_scans): per-stream raw-scan staging (host pinned + device), item rows, row count
+        self.submap = None
+        self.row_factor = 2.5             # item rows (scan + radius submap, duplicates kept) per scan point the buffers are sized for
+        self._raw_pin = [None] * S
+        self._raw_dev = [None] * S
+        self._rows = [None] * S
+        self._nrows = [None] * S
+        self._scores = [None] * S
+        self._raw_ev = [None] * S
         self.table = None
         self.rows_used = 0
         self.prepare(max_rows, table_rows, stage_cols)
@@ -76,14 +91,23 @@ class ScanEngine:
             if table_rows:
                 self.reset_table(table_rows)
             if stage_cols and max_rows:
-                for k, st in enumerate(self.streams):
-                    with torch.cuda.stream(st):
-                        self._stage[k] = torch.empty((int(max_rows), int(stage_cols)), dtype=torch.float32, device=self.device)
+                for k in range(len(self.streams)):
+                    self._stage[k] = [torch.empty((int(max_rows), int(stage_cols)), dtype=torch.float32, device=self.device)
+                                      for _ in range(2)]
+                    self._stage_free[k] = [None, None]
             torch.cuda.synchronize(self.device)
 
     def reset_table(self, rows: int) -> None:
         if self.table is None or self.table.shape[0] < rows:
-            self.table = torch.zeros((int(rows), 8), dtype=torch.float64, device=self.device)
+            # every forward writes all 8 sums of its rows (k_points_to_blocks clears them first), so no fill is needed --
+            # a zero fill on the main stream would race with the side streams' writes.  The block is allocated on the main
+            # stream: the side streams wait for the allocation point and are recorded as users of the block.
+            with torch.cuda.device(self.device):
+                self.table = torch.empty((int(rows), 8), dtype=torch.float64, device=self.device)
+                for st in self.streams:
+                    if st is not self.main:
+                        st.wait_stream(self.main)
+                        self.table.record_stream(st)
         self.rows_used = 0
 
     # ---- steady state ----------------------------------------------------------------------------------------------
@@ -104,27 +128,148 @@ class ScanEngine:
             if not batch.is_cuda:
                 batch = self._to_device(k, batch)
             scores, _ = self.net.forward_metrics(batch, n_batches, self.table[row: row + n_batches])
+            self._release_stage()
         self.last_stream = st
         return scores
 
     def _to_device(self, k: int, host: torch.Tensor) -> torch.Tensor:
+        """Host batch -> one of stream k's two device staging buffers, copied on the engine's COPY stream: the copy of a
+        step overlaps the forwards in flight instead of sitting in front of its own forward in the stream's hardware queue
+        (where it also held back every other stream multiplexed onto that queue: 16 % of the rate at 7 streams).  The
+        forward waits for the copy's event; the copy waits for the forward that last read the buffer (two steps of this
+        stream ago)."""
         n = host.shape[0]
         if host.dtype != torch.float32 or not host.is_contiguous():
             host = host.to(torch.float32).contiguous()
-        buf = self._stage[k]
-        if buf is None or buf.shape[0] < n or buf.shape[1] != host.shape[1]:
+        slot = self._flip[k]
+        self._flip[k] = slot ^ 1
+        bufs = self._stage[k]
+        if bufs is None or bufs[0].shape[0] < n or bufs[0].shape[1] != host.shape[1]:
             cap = max(n, 1024)
-            buf = self._stage[k] = torch.empty((cap + cap // 4, host.shape[1]), dtype=torch.float32, device=self.device)
-        if not host.is_pinned():
-            if self._pinned[k] is None or self._pinned[k].shape[0] < n or self._pinned[k].shape[1] != host.shape[1]:
-                self._pinned[k] = torch.empty((max(n, buf.shape[0]), host.shape[1]), dtype=torch.float32).pin_memory()
-            # the stream's previous copy out of this pinned buffer must be done before it is overwritten
             self.streams[k].synchronize()
-            self._pinned[k][:n].copy_(host)
-            host = self._pinned[k][:n]
-        dst = buf[:n]
-        dst.copy_(host, non_blocking=True)
+            self.copy_stream.synchronize()
+            bufs = self._stage[k] = [torch.empty((cap + cap // 4, host.shape[1]), dtype=torch.float32, device=self.device)
+                                     for _ in range(2)]
+            self._stage_free[k] = [None, None]
+        if not host.is_pinned():
+            pin = self._pinned[k]
+            if pin is None or pin[0].shape[0] < n or pin[0].shape[1] != host.shape[1]:
+                pin = self._pinned[k] = [torch.empty((max(n, bufs[0].shape[0]), host.shape[1]), dtype=torch.float32).pin_memory()
+                                         for _ in range(2)]
+            if self._copied[k][slot] is not None:
+                self._copied[k][slot].synchronize()      # the copy that last read this pinned buffer is done
+            pin[slot][:n].copy_(host)
+            host = pin[slot][:n]
+        dst = bufs[slot][:n]
+        cs = self.copy_stream
+        if self._stage_free[k][slot] is not None:
+            cs.wait_event(self._stage_free[k][slot])
+        with torch.cuda.stream(cs):
+            dst.copy_(host, non_blocking=True)
+            ev = self._copied[k][slot]
+            if ev is None:
+                ev = self._copied[k][slot] = torch.cuda.Event()
+            ev.record(cs)
+        self.streams[k].wait_event(ev)
+        self._pending_slot = (k, slot)
         return dst
+
+    def _release_stage(self) -> None:
+        """Called right after the forward that reads the staging buffer was issued: marks the buffer reusable from there."""
+        if self._pending_slot is not None:
+            k, slot = self._pending_slot
+            ev = self._stage_free[k][slot]
+            if ev is None:
+                ev = self._stage_free[k][slot] = torch.cuda.Event()
+            ev.record(self.streams[k])
+            self._pending_slot = None
+
+    # ---- offline items assembled on the device (blt_dataset.py:209-244 + collate_fn :173-182) -----------------------------
+    def attach_map(self, map_xyz, radius: float) -> None:
+        """The map of the variant-A submap (reference blt_dataset.py:222-226: every map point within ``radius`` of a scan
+        point) goes to the device ONCE: a uniform cell grid owned by the first context, attached as a view to the others."""
+        from .datasets.blt_dataset import DeviceRadiusSubmap
+        with torch.cuda.device(self.device):
+            self.submap = DeviceRadiusSubmap(map_xyz, radius, device=self.device, ctx=self.ctxs[0])
+            for cx in self.ctxs[1:]:
+                cx.radius_grid_attach(self.ctxs[0])
+
+    def prepare_scans(self, max_points: int, dtype=np.float64) -> None:
+        """Raw-scan staging, item buffers and arenas of every stream sized for groups of up to ``max_points`` scan points
+        (everything that is not steady state happens before the loop)."""
+        f64 = np.dtype(dtype) == np.float64
+        tdt = torch.float64 if f64 else torch.float32
+        cap_rows = int(max_points * self.row_factor) + 1024
+        with torch.cuda.device(self.device):
+            for k, (cx, st) in enumerate(zip(self.ctxs, self.streams)):
+                with torch.cuda.stream(st):
+                    self._raw_pin[k] = torch.empty((max_points + 1024, 4), dtype=tdt).pin_memory()
+                    self._raw_dev[k] = torch.empty((max_points + 1024, 4), dtype=tdt, device=self.device)
+                    self._raw_ev[k] = torch.cuda.Event()
+                    self._rows[k] = torch.empty((cap_rows, 6), dtype=torch.float32, device=self.device)
+                    self._scores[k] = torch.empty(cap_rows, dtype=torch.float32, device=self.device)
+                    self._nrows[k] = torch.zeros(4, dtype=torch.int32, device=self.device)
+                cx.reserve(cap_rows)
+            torch.cuda.synchronize(self.device)
+
+    def submit_scans(self, scans, row: int | None = None) -> torch.Tensor:
+        """One step from RAW scans: ``scans`` = k arrays [n_j, >= 4] = (x, y, z, label) in the map frame (what
+        BacchusModule.cash_scans keeps), one batch index each.  Stream-ordered, no host synchronisation: one pinned
+        host -> device copy of the raw rows, per scan ``sps_radius_item`` (scan rows + radius submap rows appended to the
+        stream's item buffer, row count on the device), then ``sps_forward_metrics_n``.  Replaces the DataLoader worker's
+        per-item KD-tree query (blt_dataset.py:224-226,258-271), add_timestamp / stacking (:209-244) and collate_fn.
+        Returns the scores buffer of the stream ([row capacity]; the first ``n_rows`` entries are valid after finish())."""
+        if self.submap is None:
+            raise RuntimeError("attach_map(map_xyz, radius) first")
+        k = self._next
+        self._next = (k + 1) % len(self.streams)
+        st = self.streams[k]
+        nb = len(scans)
+        if row is None:
+            row = self.rows_used
+        if self.table is None or row + nb > self.table.shape[0]:
+            raise ValueError("metric table too small: call reset_table(rows) with the number of scans of the sequence")
+        self.rows_used = max(self.rows_used, row + nb)
+        arrs = [s.numpy() if torch.is_tensor(s) else np.asarray(s) for s in scans]
+        f64 = arrs[0].dtype == np.float64          # the radius test runs on the scan's own dtype (cKDTree promotes float32)
+        npdt, tdt, esz = (np.float64, torch.float64, 8) if f64 else (np.float32, torch.float32, 4)
+        n_tot = int(sum(a.shape[0] for a in arrs))
+        cap_rows = int(n_tot * self.row_factor) + 1024
+        with torch.cuda.device(self.device), torch.cuda.stream(st):
+            pin = self._raw_pin[k]
+            if pin is None or pin.dtype != tdt or pin.shape[0] < n_tot:
+                st.synchronize()
+                grow = n_tot + n_tot // 4 + 1024
+                pin = self._raw_pin[k] = torch.empty((grow, 4), dtype=tdt).pin_memory()
+                self._raw_dev[k] = torch.empty((grow, 4), dtype=tdt, device=self.device)
+                self._raw_ev[k] = torch.cuda.Event()
+            elif self._raw_ev[k] is not None:
+                self._raw_ev[k].synchronize()     # this stream's previous copy out of the pinned buffer is done
+            if self._rows[k] is None or self._rows[k].shape[0] < cap_rows:
+                grow = cap_rows + cap_rows // 4
+                self._rows[k] = torch.empty((grow, 6), dtype=torch.float32, device=self.device)
+                self._scores[k] = torch.empty(grow, dtype=torch.float32, device=self.device)
+                if self._nrows[k] is None:
+                    self._nrows[k] = torch.zeros(4, dtype=torch.int32, device=self.device)
+            host = pin.numpy()
+            o = 0
+            for a in arrs:
+                host[o: o + a.shape[0]] = a[:, :4]          # casts to the group's dtype
+                o += a.shape[0]
+            raw, rows, nrows, scores = self._raw_dev[k], self._rows[k], self._nrows[k], self._scores[k]
+            raw[:n_tot].copy_(pin[:n_tot], non_blocking=True)
+            self._raw_ev[k].record(st)
+            cx = self.ctxs[k]
+            self.net.model._sync_weights(cx)
+            o = 0
+            for j, a in enumerate(arrs):
+                cx.radius_item(raw.data_ptr() + o * 4 * esz, f64, 4, a.shape[0], float(j), None if j == 0 else nrows.data_ptr(),
+                               rows.data_ptr(), 6, rows.shape[0], nrows.data_ptr(), st.cuda_stream)
+                o += a.shape[0]
+            cx.forward_metrics_n(rows.data_ptr(), 6, rows.shape[0], nrows.data_ptr(), self.vs, self.eps, nb, scores.data_ptr(),
+                                 self.table[row: row + nb].data_ptr(), st.cuda_stream)
+        self.last_stream = st
+        return scores
 
     def use_full_arenas(self) -> None:
         """Every context back to full-size arenas (cannot overflow; re-allocated by the next forward)."""

@@ -142,20 +142,22 @@ class _TrainForward(torch.autograd.Function):
             stats = torch.zeros(plan.n_stats, dtype=torch.float32, device=dev)
             ctx.train_forward(blob.data_ptr(), blob.numel(), coordinates.data_ptr(), coordinates.stride(0), n,
                               module.voxel_size, scores.data_ptr(), stats.data_ptr(), stream)
+            generation = ctx.train_generation()     # the activations this node's backward needs live in the context
         fctx.save_for_backward(scores)
-        fctx.native = (ctx, [plan.span_of[id(p)] + (tuple(p.shape),) for p in params], blob.numel())
+        fctx.native = (ctx, [plan.span_of[id(p)] + (tuple(p.shape),) for p in params], blob.numel(), generation)
         fctx.mark_non_differentiable(stats)
         return scores, stats
 
     @staticmethod
     def backward(fctx, dscores, _dstats):
         (scores,) = fctx.saved_tensors
-        ctx, spans, numel = fctx.native
+        ctx, spans, numel, generation = fctx.native
         with torch.cuda.device(scores.device):
             stream = torch.cuda.current_stream().cuda_stream
             grad = torch.empty(numel, dtype=torch.float32, device=scores.device)
             d = dscores.to(torch.float32).contiguous()
-            ctx.train_backward(d.data_ptr(), scores.data_ptr(), grad.data_ptr(), numel, stream)
+            # fails (SpsError) if a later forward on this context overwrote the activations: no silently wrong gradients
+            ctx.train_backward(d.data_ptr(), scores.data_ptr(), grad.data_ptr(), numel, stream, generation)
             # data-parallel training (one process per GPU, scripts/train.py under torchrun): the gradient of the whole
             # network is ONE flat tensor, so the ranks exchange it with a single all-reduce (RCCL over xGMI, 7.4 MB)
             # instead of one per parameter

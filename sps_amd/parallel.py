@@ -20,12 +20,13 @@ def shard_indices(n_scans: int, rank: int, world: int):
     return list(range(rank, n_scans, world))
 
 
-def gather_metric_rows(local_rows: torch.Tensor, world: int, group=None) -> torch.Tensor:
+def gather_metric_rows(local_rows: torch.Tensor, world: int, group=None, force: bool = False) -> torch.Tensor:
     """All-gather the ranks' [n_local, ROW] rows (n_local may differ by one) -> [n_total, ROW] sorted by
-    scan index.  One padded all_gather; the pad rows carry scan_idx = -1 and are dropped."""
+    scan index.  One padded all_gather; the pad rows carry scan_idx = -1 and are dropped.  ``force`` runs the
+    collective at world size 1 too (an initialised one-rank group: exercises the RCCL path on a single-GPU box)."""
     import torch.distributed as dist
     assert local_rows.dim() == 2 and local_rows.shape[1] == ROW
-    if world == 1:
+    if world == 1 and not force:
         out = local_rows
     else:
         n_local = torch.tensor([local_rows.shape[0]], dtype=torch.int64, device=local_rows.device)

@@ -1,6 +1,8 @@
 """Shared test helpers (no GPU needed to import)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -68,3 +70,27 @@ def assert_nondegenerate(sums) -> None:
     """[count, TP, FP, FN, TN, ...]: every confusion cell must be populated, else a label comparison is vacuous."""
     s = np.asarray(sums, dtype=np.float64).reshape(-1, 8).sum(axis=0)
     assert s[1] > 0 and s[2] > 0 and s[3] > 0 and s[4] > 0, f"degenerate confusion counts TP/FP/FN/TN = {s[1:5]}"
+
+
+def write_data_tree(root, n_scans=3, seq="20220629", n_map=3000, n_pts=120, scan_dtype=np.float64):
+    """A synthetic $DATA tree in the reference's on-disk layout (blt_dataset.py:49-100)."""
+    rng = np.random.default_rng(7)
+    os.makedirs(os.path.join(root, "maps"))
+    os.makedirs(os.path.join(root, "sequence", seq, "scans"))
+    os.makedirs(os.path.join(root, "sequence", seq, "poses"))
+    pc_map = np.concatenate([rng.uniform(-4, 4, (n_map, 3)), rng.uniform(0, 1, (n_map, 2))], 1)   # 5 columns: first 4 used
+    np.save(os.path.join(root, "maps", "base_map.asc.npy"), pc_map)
+    ang = 0.3
+    T_map = np.array([[np.cos(ang), -np.sin(ang), 0, 0.5], [np.sin(ang), np.cos(ang), 0, -0.25], [0, 0, 1, 0.1], [0, 0, 0, 1.0]])
+    np.savetxt(os.path.join(root, "sequence", seq, "map_transform"), T_map, delimiter=",")
+    scans, poses = [], []
+    for i in range(n_scans):
+        pose = np.eye(4); pose[:3, 3] = [0.2 * i, -0.1 * i, 0.0]
+        world = pc_map[rng.choice(len(pc_map), n_pts, replace=False), :3] + rng.normal(0, 0.03, (n_pts, 3))
+        sensor = (np.linalg.inv(T_map @ pose) @ np.c_[world, np.ones(len(world))].T).T[:, :3]
+        scan = np.c_[sensor, rng.uniform(0, 1, len(sensor))].astype(scan_dtype)
+        stamp = f"{1656500000.0 + i:.6f}"
+        np.save(os.path.join(root, "sequence", seq, "scans", stamp + ".npy"), scan)
+        np.savetxt(os.path.join(root, "sequence", seq, "poses", stamp + ".txt"), pose, delimiter=",")
+        scans.append(scan); poses.append(pose)
+    return pc_map, T_map, scans, poses

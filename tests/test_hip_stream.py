@@ -226,7 +226,8 @@ def test_bench_driver_protocol_is_steady_state():
                   "--no-h2d"])
         assert r.returncode == 0, r.stderr[-3000:]
         out[k] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out[20]["config"]["streams_per_gpu"] == 20           # clamped to the step count
+    assert out[20]["config"]["streams_per_gpu"] == 7            # ~3 timed steps per stream, not 20 one-step pipelines
+    assert out[200]["config"]["streams_per_gpu"] == 7 and out[200]["config"]["arena_mb_all_contexts"] < 3072
     assert out[20]["value"] > 0.75 * out[200]["value"], (out[20]["value"], out[200]["value"])
     assert out[20]["mean_metrics"]["dIoU"] > 0
 
@@ -345,3 +346,21 @@ def test_inference_only_context_rulebook_replaces_neighbour_table(net):
     nb4 = torch.empty((81, V[4]), dtype=torch.int32, device="cuda")
     assert _native.lib.sps_get_nbr(cx.handle, 4, nb4.data_ptr()) == 0         # ... the coarse levels keep theirs
     cx.set_inference_only(False)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_path_runs_at_world_size_one():
+    """No multi-GPU node is available to the tests, so the RCCL code path (init_process_group("nccl", device_id=...), the
+    metric-table all_gather, barrier, destroy) is executed through librccl at world size 1, launched the way the driver
+    launches the N-GPU bench (torch.distributed.run, one rank per GPU) -- bench.py and scripts/predict.py, in child
+    processes that touch the GPU only after the launcher has started them."""
+    base = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1"]
+    r = _run(base + ["--master-port", "29541", "bench.py", "--gpus", "1", "--force-dist", "--steps", "12", "--warmup", "3",
+                     "--azimuth", "500", "--streams", "3", "--no-cpu-baseline", "--no-stages"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["mean_metrics"]["dIoU"] > 0
+    r = _run(base + ["--master-port", "29542", os.path.join("scripts", "predict.py"), "--synthetic", "6", "-c",
+                     os.path.join("config", "config.yaml"), "--force-dist", "--streams", "3"])
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "dIoU" in r.stdout and "Loss" in r.stdout

@@ -228,3 +228,78 @@ def test_training_step_with_the_reference_batch_of_two_scans():
     with torch.enable_grad():
         s = net(torch.from_numpy(twice).cuda()).detach().cpu().numpy()
     np.testing.assert_allclose(s[: len(a)], s[len(a):], rtol=0, atol=2e-6)
+
+
+@pytest.mark.timeout(1200)
+def test_training_gradients_at_scale_batch_of_two():
+    """The reference's training batch (config.yaml: BATCH_SIZE 2; models.py:62-70) at tens of thousands of rows: the
+    multi-chunk ordered reductions of k_wgrad, the 256-partial BatchNorm finish and conv0's 4096-wave weight gradient are
+    DIFFED against the float64 autograd oracle, not just timed (the small-scene tests never leave their first chunk)."""
+    b1 = synthetic.small_scene(seed=3, n_scan=24000, extent=22.0)
+    b2 = synthetic.small_scene(seed=4, n_scan=24000, extent=22.0)
+    b2[:, 0] = 1
+    batch = np.concatenate([b1, b2])
+    assert len(batch) >= 60000
+    params = O.random_params(seed=0)
+    loss_ref, scores_ref, grads_ref, stats_ref = T.train_step(params, batch, VS)
+    net, out, grads = native_step(params, batch)
+    from sps_amd.models.models import get_context
+    V = get_context(0).level_counts()
+    assert V[0] >= 40000 and V[4] >= 64, V
+    assert float(out["loss"].detach()) == pytest.approx(loss_ref, rel=5e-5)
+    worst = {}
+    for name, want in grads_ref.items():
+        got = grads[name].reshape(want.shape)
+        assert np.isfinite(got).all(), name
+        worst[name] = rel_err(got, want)
+    bad = {k: v for k, v in worst.items() if v > 3e-3}
+    assert not bad, f"gradient mismatch (relative to the tensor's max): {bad}"
+    sd = {k.replace("model.MinkUNet.", ""): v.detach().cpu().numpy() for k, v in net.state_dict().items()}
+    for bn, (mean, var, n) in stats_ref.items():
+        np.testing.assert_allclose(sd[bn + ".bn.running_mean"], 0.9 * params[bn + ".bn.running_mean"] + 0.1 * mean,
+                                   rtol=0, atol=5e-5, err_msg=bn)
+
+
+def test_backward_refuses_overwritten_activations():
+    """The activations a backward reads live in the native context: a later forward on the same context (a second training
+    forward before one backward, an evaluation forward issued mid-step) must make the stale node's backward FAIL, not
+    return the gradients of the wrong forward (sps_train_backward_at)."""
+    from sps_amd._native import SpsError
+    b1 = synthetic.small_scene(seed=3, n_scan=900)
+    b2 = synthetic.small_scene(seed=9, n_scan=700)
+    net = net_from_params(O.random_params(seed=0)).cuda().train()
+    d1, d2 = torch.from_numpy(b1).cuda(), torch.from_numpy(b2).cuda()
+    l1 = net.training_step(d1, 0)["loss"]
+    l2 = net.training_step(d2, 1)["loss"]                       # overwrites the activations of step 1
+    l2.backward()                                               # the live forward: fine
+    with pytest.raises((SpsError, RuntimeError), match="overwritten"):
+        l1.backward()
+    net.zero_grad()
+    l3 = net.training_step(d1, 2)["loss"]
+    net.eval()
+    with torch.no_grad():
+        net(d2)                                                 # an evaluation forward on the same context, mid-step
+    net.train()
+    with pytest.raises((SpsError, RuntimeError), match="overwritten"):
+        l3.backward()
+    # and the normal sequence still works afterwards
+    net.zero_grad()
+    net.training_step(d1, 3)["loss"].backward()
+    assert all(torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_train_mode_batchnorm_refuses_a_single_row():
+    """nn.BatchNorm1d (ME.MinkowskiBatchNorm in the reference, resnet.py:100-107) raises on one value per channel in
+    training mode; a cloud that collapses to a single voxel at a coarse level is reported, not silently normalised."""
+    from sps_amd._native import ERR_INVALID, SpsError
+    from sps_amd.models.models import get_context
+    rng = np.random.default_rng(0)
+    xyz = rng.uniform(0.05, 1.5, (300, 3)).astype(np.float32)   # one voxel at tensor stride 16
+    batch = np.c_[np.zeros(300), xyz, np.ones(300), rng.uniform(0, 1, 300)].astype(np.float32)
+    net = net_from_params(O.random_params(seed=0)).cuda().train()
+    net.training_step(torch.from_numpy(batch).cuda(), 0)
+    cx = get_context(0)
+    assert cx.level_counts()[4] == 1
+    with pytest.raises(SpsError) as e:
+        cx.check_errors(torch.cuda.current_stream().cuda_stream)
+    assert e.value.code == ERR_INVALID and "more than 1 value" in str(e.value)

@@ -159,27 +159,7 @@ def test_roofline_bookkeeping_reproduces_survey_numbers():
 
 
 # ------------------------------------------------------------------ $DATA tree reader (blt_dataset.py:26-100)
-def _write_data_tree(root, n_scans=3, seq="20220629"):
-    rng = np.random.default_rng(7)
-    os.makedirs(os.path.join(root, "maps"))
-    os.makedirs(os.path.join(root, "sequence", seq, "scans"))
-    os.makedirs(os.path.join(root, "sequence", seq, "poses"))
-    pc_map = np.concatenate([rng.uniform(-4, 4, (3000, 3)), rng.uniform(0, 1, (3000, 2))], 1)   # 5 columns: first 4 used
-    np.save(os.path.join(root, "maps", "base_map.asc.npy"), pc_map)
-    ang = 0.3
-    T_map = np.array([[np.cos(ang), -np.sin(ang), 0, 0.5], [np.sin(ang), np.cos(ang), 0, -0.25], [0, 0, 1, 0.1], [0, 0, 0, 1.0]])
-    np.savetxt(os.path.join(root, "sequence", seq, "map_transform"), T_map, delimiter=",")
-    scans, poses = [], []
-    for i in range(n_scans):
-        pose = np.eye(4); pose[:3, 3] = [0.2 * i, -0.1 * i, 0.0]
-        world = pc_map[rng.choice(len(pc_map), 120, replace=False), :3] + rng.normal(0, 0.03, (120, 3))
-        sensor = (np.linalg.inv(T_map @ pose) @ np.c_[world, np.ones(len(world))].T).T[:, :3]
-        scan = np.c_[sensor, rng.uniform(0, 1, len(sensor))].astype(np.float64)
-        stamp = f"{1656500000.0 + i:.6f}"
-        np.save(os.path.join(root, "sequence", seq, "scans", stamp + ".npy"), scan)
-        np.savetxt(os.path.join(root, "sequence", seq, "poses", stamp + ".txt"), pose, delimiter=",")
-        scans.append(scan); poses.append(pose)
-    return pc_map, T_map, scans, poses
+from tests.helpers import write_data_tree as _write_data_tree  # noqa: E402
 
 
 def test_bacchus_module_reads_data_tree(tmp_path, monkeypatch):
@@ -282,3 +262,19 @@ def test_save_vis_dumps(tmp_path):
     two = torch.cat([batch, torch.cat([torch.ones(12, 1), batch[:, 1:]], dim=1)])
     with pytest.raises(AssertionError):
         save_vis(str(tmp_path / "p2"), two, 0, torch.cat([scores, scores]))
+
+
+def test_product_library_has_no_diagnostic_switches():
+    """The shipped libsps_hip.so reads no environment variable and contains none of the diagnostic switches: they exist in
+    private -DSPS_DIAG builds only (tools/*_sweep.sh load those through $SPS_LIB)."""
+    import re
+    import subprocess
+    from sps_amd import _build
+    lib = _build.build()
+    blob = open(lib, "rb").read()
+    for name in (b"SPS_DIAG_SKIP", b"SPS_NO_MERGE", b"SPS_PX", b"SPS_GRID_SCALE", b"SPS_CONV_MAX_WG", b"SPS_GEOM_L",
+                 b"SPS_ABLATE", b"SPS_WAVE_TRACE", b"SPS_TRACE_LAYER", b"SPS_WS_"):
+        assert name not in blob, name
+    assert not re.search(rb"SPS_[A-Z][A-Z_0-9]{3,}", blob), re.findall(rb"SPS_[A-Z][A-Z_0-9]{3,}", blob)[:5]
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
