@@ -16,9 +16,10 @@ sigmoid + the per-scan metric sums (written to a row of a device table).  It run
 `value` is always scans/s (config 3 processes 4 scans per step).
 
 Everything that is not steady state (arena, weight upload, one forward per context) happens in ScanEngine.prepare()
-before the timed region, whatever --warmup is; streams are clamped to the step count.  After the resident-input
-region a second, separately reported region feeds every step from a pinned HOST buffer (`h2d_inclusive`, SURVEY
-8(d)); it is never `value`.
+before the timed region, whatever --warmup is; short runs use fewer streams (about three timed steps per stream).
+`value` is measured with every step's [N,6] batch copied from a pinned HOST buffer to the device inside the timed region
+("H2D of the input included"); the same steps with the inputs already resident in HBM are timed first and
+reported next to it (`resident_inputs`).
 
 Scans are sharded data-parallel (each rank owns its scans; weak scaling); the only exchange is one RCCL all-gather of
 the per-scan metric rows at the end of the sequence, inside the timed region.

@@ -50,7 +50,9 @@ def synthetic_loaders(n, voxel_size):
 @click.option("--synthetic", "n_synth", type=int, default=0, help="train on N synthetic scans instead of $DATA")
 @click.option("--max-epochs", type=int, default=None, help="override TRAIN.MAX_EPOCH")
 @click.option("--out", type=str, default=LOG_DIR, help="directory for checkpoints")
-def main(config, n_synth, max_epochs, out):
+@click.option("--host-items", is_flag=True, help="assemble the items on the host (DataLoader workers + scipy cKDTree, as the "
+                                                 "reference does) instead of on the device")
+def main(config, n_synth, max_epochs, out, host_items):
     cfg = yaml.safe_load(open(config))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     backend = os.environ.get("SPS_DIST_BACKEND", "nccl")          # gloo only to exercise the control flow on one GPU
@@ -69,14 +71,25 @@ def main(config, n_synth, max_epochs, out):
     torch.manual_seed(0)
 
     # Load data and model (train.py:33-35)
-    train_sampler = None          # set when every rank loads its own shard; else batch i -> rank i mod W of a common list
+    train_sampler = None          # DistributedSampler of the host path under torchrun
+    loaders_sharded = False       # every rank iterates only its own batches; else batch i -> rank i mod W of a common list
     if n_synth:
         train_loader, val_loader = synthetic_loaders(n_synth, cfg["MODEL"]["VOXEL_SIZE"])
     else:
         data = datasets.BacchusModule(cfg)
-        data.setup()
+        if not host_items:
+            # the per-item work (radius submap, stacking, collate, augmentation) runs on the GPU: no KD-trees, no workers;
+            # under torchrun every rank assembles only its own batches
+            data.train_loader = datasets.DeviceItemLoader(cfg, data.train_scans, data.map, split="train", shuffle=cfg["DATA"]["SHUFFLE"],
+                                                          device=dev, shard=(rank, world), even_shards=True)
+            data.valid_loader = datasets.DeviceItemLoader(cfg, data.val_scans, data.map, shuffle=False, device=dev,
+                                                          shard=(rank, world))
+            loaders_sharded = world > 1
+        else:
+            data.setup()
         train_loader, val_loader = data.train_dataloader(), data.val_dataloader()
-        if world > 1:
+        if world > 1 and host_items:
+            loaders_sharded = True
             # every rank LOADS only its own shard (the per-item KD-tree query and the augmentation are the expensive part of
             # an item): a DistributedSampler over the training set (same number of samples on every rank, reshuffled per
             # epoch from the epoch number), every W-th item of the validation set
@@ -105,8 +118,8 @@ def main(config, n_synth, max_epochs, out):
     for epoch in range(epochs):
         model.train()
         t0, losses = time.time(), []
-        sharded = train_sampler is not None
-        if sharded:
+        sharded = loaders_sharded
+        if train_sampler is not None:
             train_sampler.set_epoch(epoch)
         n_even = len(train_loader) if sharded else len(train_loader) // world * world     # the same number of steps on every rank
         for i, batch in enumerate(train_loader):

@@ -67,7 +67,17 @@ class BacchusModule:
                           shuffle=shuffle, num_workers=self.cfg["DATA"]["NUM_WORKER"], pin_memory=True,
                           drop_last=False, timeout=0)
 
-    def setup(self, stage=None):
+    def setup(self, stage=None, device_items=False):
+        """``device_items``: the per-item work (radius submap, stacking, collate, augmentation) runs on the GPU
+        (DeviceItemLoader) instead of in DataLoader workers with scipy KD-trees; same batches, same random draws."""
+        if device_items:
+            if self.test:
+                self.test_loader = DeviceItemLoader(self.cfg, self.test_scans, self.map, shuffle=False)
+            else:
+                self.train_loader = DeviceItemLoader(self.cfg, self.train_scans, self.map, split='train',
+                                                     shuffle=self.cfg["DATA"]["SHUFFLE"])
+                self.valid_loader = DeviceItemLoader(self.cfg, self.val_scans, self.map, shuffle=False)
+            return
         if self.test:
             self.test_loader = self._loader(BacchusDataset(self.cfg, self.test_scans, self.map), False)
         else:
@@ -204,3 +214,116 @@ def device_item(dataset: BacchusDataset, idx: int, submap: DeviceRadiusSubmap) -
     m = torch.as_tensor(np.asarray(dataset.map[:, :3])).to(dev)[sub_idx].to(torch.float32)
     sub_rows = torch.cat([m, torch.zeros(len(m), 1, device=dev), torch.ones(len(m), 1, device=dev)], 1)
     return torch.cat([scan_rows, sub_rows], 0)
+
+
+class DeviceItemLoader:
+    """``DataLoader(BacchusDataset(...), batch_size, shuffle, collate_fn)`` (blt_dataset.py:102-118,185-278) with every
+    per-item step on the MI355X: the cached scan goes to the device raw, ``sps_radius_item`` writes the scan rows and the
+    radius-submap rows of every item of the batch into one [N, 6] tensor (collate layout), the training augmentation is
+    applied to each item's xyz there.  One host synchronisation per batch (the row counts).  The global torch generator is
+    consumed exactly as a DataLoader with ``num_workers=0`` consumes it (base-seed draw, RandomSampler seed draw, then the
+    augmentation draws item by item), so a seeded run sees the same batches as the host path."""
+
+    def __init__(self, cfg, scans, pc_map, split=None, shuffle=False, device=None, row_factor: float = 2.5,
+                 shard=(0, 1), even_shards=False):
+        """``shard`` = (rank, world): this process takes every world-th batch position of the common order (every rank draws
+        the same permutation from its identically seeded generator); ``even_shards`` drops the tail so that every rank takes
+        the same number of steps (training: one gradient all-reduce per step)."""
+        self.shard = (int(shard[0]), int(shard[1]))
+        self.even_shards = bool(even_shards)
+        self.cfg = cfg
+        self.scans = scans
+        self.map = pc_map
+        self.batch_size = int(cfg["TRAIN"]["BATCH_SIZE"])
+        self.shuffle = bool(shuffle)
+        self.augment = bool(cfg["TRAIN"]["AUGMENTATION"]) and split == "train"
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.row_factor = float(row_factor)
+        self._submap = None
+        self._raw = self._pin = self._rows = self._nrows = None
+        self.dataset = scans         # len(loader.dataset), as callers of a DataLoader expect
+
+    def _batches(self, order):
+        groups = [order[i: i + self.batch_size] for i in range(0, len(order), self.batch_size)]
+        rank, world = self.shard
+        if self.even_shards:
+            groups = groups[: len(groups) // world * world]
+        return groups[rank::world]
+
+    def __len__(self):
+        return len(self._batches(list(range(len(self.scans)))))
+
+    def _ctx(self):
+        from ..models import models
+        with torch.cuda.device(self.device):
+            cx = models.get_context(self.device.index or 0, torch.cuda.current_stream().cuda_stream)
+            if self._submap is None or self._submap.ctx is not cx:
+                self._submap = DeviceRadiusSubmap(self.map[:, :3], self.cfg["MODEL"]["VOXEL_SIZE"], device=self.device, ctx=cx)
+        return cx
+
+    def collate(self, idxs) -> torch.Tensor:
+        """[sum N, 6] float32 device tensor = collate_fn([dataset[i] for i in idxs])."""
+        from .._native import ERR_NOMEM, SpsError
+        arrs = [np.asarray(self.scans[i]) for i in idxs]
+        f64 = arrs[0].dtype == np.float64
+        tdt, esz = (torch.float64, 8) if f64 else (torch.float32, 4)
+        n_tot = int(sum(len(a) for a in arrs))
+        cx = self._ctx()
+        with torch.cuda.device(self.device):
+            st = torch.cuda.current_stream()
+            if self._pin is None or self._pin.dtype != tdt or self._pin.shape[0] < n_tot:
+                st.synchronize()
+                self._pin = torch.empty((n_tot + n_tot // 4 + 1024, 4), dtype=tdt).pin_memory()
+                self._raw = torch.empty_like(self._pin, device=self.device)
+            self._nrows = torch.zeros(max(len(arrs), 4), dtype=torch.int32, device=self.device)
+            host = self._pin.numpy()
+            o = 0
+            for a in arrs:
+                host[o: o + len(a)] = a[:, :4]
+                o += len(a)
+            while True:
+                cap = int(n_tot * self.row_factor) + 1024
+                if self._rows is None or self._rows.shape[0] < cap:
+                    self._rows = torch.empty((cap, 6), dtype=torch.float32, device=self.device)
+                self._raw[:n_tot].copy_(self._pin[:n_tot], non_blocking=True)
+                o = 0
+                for j, a in enumerate(arrs):
+                    cx.radius_item(self._raw.data_ptr() + o * 4 * esz, f64, 4, len(a), float(j),
+                                   None if j == 0 else self._nrows[j - 1:].data_ptr(), self._rows.data_ptr(), 6,
+                                   self._rows.shape[0], self._nrows[j:].data_ptr(), st.cuda_stream)
+                    o += len(a)
+                ends = self._nrows[: len(arrs)].tolist()          # the one synchronisation of the batch
+                try:
+                    cx.check_errors(st.cuda_stream)
+                    break
+                except SpsError as e:
+                    if e.code != ERR_NOMEM:
+                        raise
+                    self.row_factor *= 2.0                         # denser map than the buffers were sized for
+            batch = self._rows[: ends[-1]].clone()
+            if self.augment:                                      # blt_dataset.py:240-242: scan and submap of an item together
+                a0 = 0
+                for b0 in ends:
+                    batch[a0:b0, 1:4] = BacchusDataset.augment_data(None, batch[a0:b0, 1:4])
+                    a0 = b0
+        return batch
+
+    def __iter__(self):
+        n = len(self.scans)
+        torch.empty((), dtype=torch.int64).random_()              # DataLoader's per-iterator base seed (worker seeding)
+        if self.shuffle:
+            g = torch.Generator()
+            g.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))      # RandomSampler's own generator
+            order = torch.randperm(n, generator=g).tolist()
+        else:
+            order = list(range(n))
+        mine = {tuple(g) for g in self._batches(order)}
+        for i in range(0, n, self.batch_size):
+            idxs = order[i: i + self.batch_size]
+            if tuple(idxs) in mine:
+                yield self.collate(idxs)
+            elif self.augment:
+                # another rank's batch: take (and drop) the augmentation draws of its items, so that the union of the
+                # ranks' batches is exactly the single-process epoch and every rank's generator stays in step
+                for _ in idxs:
+                    torch.rand(1), torch.randn(3), torch.rand(1), torch.rand(1), torch.rand(1, 3)

@@ -52,11 +52,8 @@ class ScanEngine:
         self._stage = [None] * S          # per-stream PAIR of device staging buffers for host batches
         self._pinned = [None] * S         # (pageable host batches only: pinned bounce buffers)
         self._flip = [0] * S
-        self._stage_free = [[None, None] for _ in range(S)]   # event: the forward that read the buffer was issued ... and done
-        self._copied = [[None, None] for _ in range(S)]       # event: the copy into the buffer is done
-        self._pending_slot = None
-        with torch.cuda.device(self.device):
-            self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._copied = [[None, None] for _ in range(S)]       # event behind the copy into the buffer
+        self._done = [None] * S                               # event behind the last host-fed forward of the stream
         # device item path (attach_map / submit_scans): per-stream raw-scan staging (host pinned + device), item rows, row count
         self.submap = None
         self.row_factor = 2.5             # item rows (scan + radius submap, duplicates kept) per scan point the buffers are sized for
@@ -94,7 +91,6 @@ class ScanEngine:
                 for k in range(len(self.streams)):
                     self._stage[k] = [torch.empty((int(max_rows), int(stage_cols)), dtype=torch.float32, device=self.device)
                                       for _ in range(2)]
-                    self._stage_free[k] = [None, None]
             torch.cuda.synchronize(self.device)
 
     def reset_table(self, rows: int) -> None:
@@ -113,9 +109,16 @@ class ScanEngine:
     # ---- steady state ----------------------------------------------------------------------------------------------
     def submit(self, batch: torch.Tensor, n_batches: int = 1, row: int | None = None) -> torch.Tensor:
         """One step: ``batch`` [N,6] = (b,x,y,z,t,label) rows with b < n_batches (BacchusModule.collate_fn layout).
-        A host tensor is copied to the device on the scan's stream (pinned staging, asynchronous).  The metric sums of
-        batch index b go to table row ``row + b`` (default: the next free rows).  Returns the scores [N] (device tensor,
-        valid after finish() or a wait on stream ``self.last_stream``)."""
+        A host tensor is copied to the device on the scan's stream (pinned source, asynchronous) into one of the stream's
+        TWO staging buffers, with an event recorded right behind the copy.  The metric sums of batch index b go to table row
+        ``row + b`` (default: the next free rows).  Returns the scores [N] (device tensor, valid after finish() or a wait
+        on stream ``self.last_stream``).
+
+        Measured (tools/streams_h2d_sweep.sh, tools/h2d_probe*.py): with the two buffers and the event
+        behind the copy the host-fed loop runs within 3 % of the resident-input loop at 7 streams (3 678 vs 3 776 scans/s);
+        one staging buffer and no event: 16 % below it.  A dedicated copy stream is worse either way: a device-side wait
+        on the copy's event (hipStreamWaitEvent behind an SDMA copy) costs the HOST 0.3 ms per step, a host-side wait
+        0.17 ms."""
         k = self._next
         self._next = (k + 1) % len(self.streams)
         st = self.streams[k]
@@ -125,19 +128,23 @@ class ScanEngine:
             raise ValueError("metric table too small: call reset_table(rows) with the number of scans of the sequence")
         self.rows_used = max(self.rows_used, row + n_batches)
         with torch.cuda.device(self.device), torch.cuda.stream(st):
-            if not batch.is_cuda:
+            host_fed = not batch.is_cuda
+            if host_fed:
                 batch = self._to_device(k, batch)
             scores, _ = self.net.forward_metrics(batch, n_batches, self.table[row: row + n_batches])
-            self._release_stage()
+            if host_fed:
+                # an event behind the forward as well (measured: without it the host-fed loop runs 14 % slower, 3 170 vs
+                # 3 678 scans/s at 7 streams -- the marker makes the runtime hand the stream's pending copy + kernels to
+                # the hardware queue at once)
+                ev = self._done[k]
+                if ev is None:
+                    ev = self._done[k] = torch.cuda.Event()
+                ev.record(st)
         self.last_stream = st
         return scores
 
     def _to_device(self, k: int, host: torch.Tensor) -> torch.Tensor:
-        """Host batch -> one of stream k's two device staging buffers, copied on the engine's COPY stream: the copy of a
-        step overlaps the forwards in flight instead of sitting in front of its own forward in the stream's hardware queue
-        (where it also held back every other stream multiplexed onto that queue: 16 % of the rate at 7 streams).  The
-        forward waits for the copy's event; the copy waits for the forward that last read the buffer (two steps of this
-        stream ago)."""
+        """Host batch -> the next of stream k's two device staging buffers, on stream k (the caller's current stream)."""
         n = host.shape[0]
         if host.dtype != torch.float32 or not host.is_contiguous():
             host = host.to(torch.float32).contiguous()
@@ -146,43 +153,24 @@ class ScanEngine:
         bufs = self._stage[k]
         if bufs is None or bufs[0].shape[0] < n or bufs[0].shape[1] != host.shape[1]:
             cap = max(n, 1024)
-            self.streams[k].synchronize()
-            self.copy_stream.synchronize()
             bufs = self._stage[k] = [torch.empty((cap + cap // 4, host.shape[1]), dtype=torch.float32, device=self.device)
                                      for _ in range(2)]
-            self._stage_free[k] = [None, None]
         if not host.is_pinned():
             pin = self._pinned[k]
             if pin is None or pin[0].shape[0] < n or pin[0].shape[1] != host.shape[1]:
                 pin = self._pinned[k] = [torch.empty((max(n, bufs[0].shape[0]), host.shape[1]), dtype=torch.float32).pin_memory()
                                          for _ in range(2)]
             if self._copied[k][slot] is not None:
-                self._copied[k][slot].synchronize()      # the copy that last read this pinned buffer is done
+                self._copied[k][slot].synchronize()       # the copy that last read this pinned bounce buffer is done
             pin[slot][:n].copy_(host)
             host = pin[slot][:n]
         dst = bufs[slot][:n]
-        cs = self.copy_stream
-        if self._stage_free[k][slot] is not None:
-            cs.wait_event(self._stage_free[k][slot])
-        with torch.cuda.stream(cs):
-            dst.copy_(host, non_blocking=True)
-            ev = self._copied[k][slot]
-            if ev is None:
-                ev = self._copied[k][slot] = torch.cuda.Event()
-            ev.record(cs)
-        self.streams[k].wait_event(ev)
-        self._pending_slot = (k, slot)
+        dst.copy_(host, non_blocking=True)
+        ev = self._copied[k][slot]
+        if ev is None:
+            ev = self._copied[k][slot] = torch.cuda.Event()
+        ev.record(self.streams[k])
         return dst
-
-    def _release_stage(self) -> None:
-        """Called right after the forward that reads the staging buffer was issued: marks the buffer reusable from there."""
-        if self._pending_slot is not None:
-            k, slot = self._pending_slot
-            ev = self._stage_free[k][slot]
-            if ev is None:
-                ev = self._stage_free[k][slot] = torch.cuda.Event()
-            ev.record(self.streams[k])
-            self._pending_slot = None
 
     # ---- offline items assembled on the device (blt_dataset.py:209-244 + collate_fn :173-182) -----------------------------
     def attach_map(self, map_xyz, radius: float) -> None:

@@ -339,7 +339,8 @@ class SPSNet(nn.Module):
         return [optimizer], [scheduler]
 
     @torch.no_grad()
-    def forward_metrics(self, batch: torch.Tensor, n_batches: int = 1, out: torch.Tensor | None = None):
+    def forward_metrics(self, batch: torch.Tensor, n_batches: int = 1, out: torch.Tensor | None = None,
+                        scores: torch.Tensor | None = None):
         """forward + the per-batch-index metric sums of predict_step in ONE native call (sps_forward_metrics): returns
         (scores [N], sums float64 [n_batches, 8] on the device).  ``batch`` rows are (b,x,y,z,t,label); ``out`` may be
         a preallocated contiguous float64 device tensor of n_batches * 8 elements (e.g. a row of a results table)."""
@@ -353,7 +354,10 @@ class SPSNet(nn.Module):
             ctx = get_context(batch.device.index or 0, stream)
             self.model._sync_weights(ctx)
             n = batch.shape[0]
-            scores = torch.empty(n, dtype=torch.float32, device=batch.device)
+            if scores is None:
+                scores = torch.empty(n, dtype=torch.float32, device=batch.device)
+            elif scores.dtype != torch.float32 or not scores.is_contiguous() or scores.numel() < n or not scores.is_cuda:
+                raise ValueError("scores must be a contiguous float32 device tensor with at least N elements")
             if out is None:
                 out = torch.empty((n_batches, 8), dtype=torch.float64, device=batch.device)
             elif out.dtype != torch.float64 or not out.is_contiguous() or out.numel() != n_batches * 8 or not out.is_cuda:

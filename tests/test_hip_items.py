@@ -181,3 +181,76 @@ def test_predict_cli_real_data_branch_device_items_match_host_items(tmp_path):
         outs[name] = [lines[k] for k in ("Loss", "R2", "dIoU", "Precision", "Recall", "F1")]
     assert outs["device-b1"] == outs["device-b4"] == outs["host-b4"], outs
     assert float(outs["host-b4"][2].split()[-1]) > 0, "degenerate dIoU"
+
+
+def _batches_close(dev_batches, host_batches, augmented):
+    assert len(dev_batches) == len(host_batches)
+    for d, h in zip(dev_batches, host_batches):
+        d, h = d.cpu().numpy(), h.numpy()
+        assert d.shape == h.shape
+        for b in np.unique(h[:, 0]):
+            db, hb = d[d[:, 0] == b], h[h[:, 0] == b]
+            ns = int((hb[:, 4] == 1).sum())
+            np.testing.assert_array_equal(db[:, [0, 4, 5]][:ns], hb[:, [0, 4, 5]][:ns])
+            if not augmented:
+                np.testing.assert_array_equal(db[:ns], hb[:ns])
+                np.testing.assert_array_equal(_sorted_rows(db[ns:]), _sorted_rows(hb[ns:]))
+            else:   # float32 matmul on the GPU vs on the CPU: rounding only; the submap rows arrive in another order
+                np.testing.assert_allclose(db[:ns, 1:4], hb[:ns, 1:4], rtol=0, atol=2e-5)
+                assert len(db) == len(hb)
+                np.testing.assert_allclose(np.sort(db[ns:, 1:4], 0), np.sort(hb[ns:, 1:4], 0), rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("augment", [False, True])
+def test_device_item_loader_reproduces_the_dataloader(augment):
+    """DeviceItemLoader == DataLoader(BacchusDataset, batch_size, shuffle, collate_fn) with num_workers = 0 under the same
+    seed: same shuffled order (RandomSampler's draws), same items, same augmentation draws (blt_dataset.py:102-118,240-278)."""
+    import sps.datasets.blt_dataset as blt
+    from torch.utils.data import DataLoader
+    cfg = _cfg()
+    cfg["TRAIN"] = dict(cfg["TRAIN"], BATCH_SIZE=2, AUGMENTATION=augment)
+    cfg["DATA"] = dict(cfg["DATA"], SHUFFLE=True)
+    pc_map, scans = _scene(n_map=8000, n_scan=700)
+    scans = scans + [s[::-1].copy() for s in scans[:2]]                       # 5 items -> 3 batches, the last one partial
+    ds = blt.BacchusDataset(cfg, scans, pc_map, split="train")
+    torch.manual_seed(5)
+    host = list(DataLoader(ds, batch_size=2, shuffle=True, collate_fn=blt.BacchusModule.collate_fn, num_workers=0))
+    after_host = torch.rand(1).item()
+    dl = blt.DeviceItemLoader(cfg, scans, pc_map, split="train", shuffle=True, device="cuda:0")
+    torch.manual_seed(5)
+    dev = list(dl)
+    assert torch.rand(1).item() == after_host, "the loader must consume the global generator exactly as the DataLoader does"
+    assert len(dl) == 3 and len(dl.dataset) == 5
+    _batches_close(dev, host, augment)
+    # two ranks: every rank takes every second batch of the same order; the tail is dropped for equal step counts
+    torch.manual_seed(5)
+    r0 = list(blt.DeviceItemLoader(cfg, scans, pc_map, split="train", shuffle=True, device="cuda:0", shard=(0, 2), even_shards=True))
+    torch.manual_seed(5)
+    r1 = list(blt.DeviceItemLoader(cfg, scans, pc_map, split="train", shuffle=True, device="cuda:0", shard=(1, 2), even_shards=True))
+    assert len(r0) == len(r1) == 1
+    _batches_close(r0 + r1, host[:2], augment)
+
+
+@pytest.mark.timeout(1200)
+def test_train_cli_on_a_data_tree_with_device_items(tmp_path):
+    """scripts/train.py on a $DATA tree (reference scripts/train.py:21-58): device items by default, --host-items for the
+    reference's DataLoader path; both train one epoch, write a checkpoint and report finite losses."""
+    import yaml
+    write_data_tree(str(tmp_path), n_scans=4, seq="train0", n_map=20000, n_pts=1500)
+    import shutil
+    for seq in ("val0",):
+        shutil.copytree(tmp_path / "sequence" / "train0", tmp_path / "sequence" / seq)
+    cfg = _cfg()
+    cfg["DATA"]["SPLIT"] = {"TRAIN": ["train0"], "VAL": ["val0"], "TEST": ["val0"]}
+    cfg["TRAIN"] = dict(cfg["TRAIN"], BATCH_SIZE=2, AUGMENTATION=True, MAX_EPOCH=1)
+    cfg_path = tmp_path / "config.yaml"
+    cfg_path.write_text(yaml.safe_dump(cfg))
+    for extra in ([], ["--host-items"]):
+        out = tmp_path / ("out_host" if extra else "out_dev")
+        r = _run([sys.executable, os.path.join("scripts", "train.py"), "-c", str(cfg_path), "--max-epochs", "1", "--out", str(out)] + extra,
+                 {"DATA": str(tmp_path)})
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("epoch 000")][0]
+        tl, vl = float(line.split("train_loss")[1].split()[0]), float(line.split("val_loss")[1].split()[0])
+        assert np.isfinite(tl) and np.isfinite(vl) and 0 < tl < 1 and 0 < vl < 1, line
+        assert any(f.endswith(".ckpt") for f in os.listdir(out / "BLT" / "checkpoints"))
