@@ -34,6 +34,7 @@ extern "C" {
 #define SPS_ERR_NOMEM (-3)   /* device allocation failed / compact arena overflow */
 #define SPS_ERR_RANGE (-4)   /* a coordinate does not fit the 64-bit voxel key   */
 #define SPS_ERR_NOWEIGHTS (-5)
+#define SPS_ERR_ITEMCAP (-6) /* sps_radius_item: the caller's item buffer is too small   */
 
 #define SPS_NUM_LEVELS 5 /* tensor strides 1,2,4,8,16 (minkunet.py:161-219) */
 
@@ -241,7 +242,7 @@ int sps_radius_grid_attach(sps_ctx *ctx, sps_ctx *owner);
  * with b = batch_index and the m map points within r of some scan point (one list per scan point, duplicates kept, as
  * sps_radius_count / sps_radius_fill), and *n_rows_dev = *row_off_dev + n + m: chaining calls with
  * row_off_dev = n_rows_dev appends the items of a batch.  Rows beyond row_cap are dropped and the next synchronising
- * call (sps_check) returns SPS_ERR_NOMEM. */
+ * call (sps_check) returns SPS_ERR_ITEMCAP. */
 int sps_radius_item(sps_ctx *ctx, const void *scan_dev, int in_f64, int64_t ld, int64_t n, float batch_index,
                     const int32_t *row_off_dev, float *rows_dev, int64_t ldo, int64_t row_cap, int32_t *n_rows_dev,
                     void *stream);

@@ -137,12 +137,13 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing, force_
         # the map goes to the device once (uniform cell grid of the radius query); buffers and arenas of every stream are
         # sized for the largest group of the sequence before the loop
         eng.attach_map(data.map[:, :3], cfg["MODEL"]["VOXEL_SIZE"])
+        eng.calibrate_rows(raw_scans[:: max(1, len(raw_scans) // 4)][:4])          # item rows per scan point of this map
         eng.prepare_scans(max(sum(len(s) for s in g) for g in batched(raw_scans, batch_size)), raw_scans[0].dtype)
     import time
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    from sps_amd._native import ERR_NOMEM, SpsError
-    for attempt in (0, 1):
+    from sps_amd._native import ERR_ITEMCAP, ERR_NOMEM, SpsError
+    for attempt in range(5):
         idx = []                                          # scan index of every used table row
         eng.reset_table(n_scans + batch_size)
         with torch.no_grad():
@@ -166,13 +167,17 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing, force_
         except SpsError as e:
             # a cloud whose coarse levels do not thin out like a LiDAR scan's outgrew the compact arenas (its forward was
             # aborted): evaluate the sequence again on full-size arenas
-            if e.code != ERR_NOMEM or attempt:
+            if e.code not in (ERR_NOMEM, ERR_ITEMCAP) or attempt == 4:
                 raise
-            if rank == 0:
-                print("a cloud outgrew the LiDAR-sized arenas or the item buffers: evaluating the sequence again on full-size "
-                      "arenas and larger item buffers", file=sys.stderr)
-            eng.use_full_arenas()
-            eng.row_factor *= 2.0
+            if e.code == ERR_ITEMCAP:
+                # the map is denser around some scan than the item buffers were sized for (calibrated on the first group)
+                if rank == 0:
+                    print("an item outgrew the item buffers: evaluating the sequence again with larger buffers", file=sys.stderr)
+                eng.row_factor *= 1.5
+            else:
+                if rank == 0:
+                    print("a cloud outgrew the LiDAR-sized arenas: evaluating the sequence again on full-size arenas", file=sys.stderr)
+                eng.use_full_arenas()
     n_local = len(idx)
     local_rows = torch.empty((n_local, parallel.ROW), dtype=torch.float64, device=dev)
     local_rows[:, 0] = torch.tensor(idx, dtype=torch.float64, device=dev)

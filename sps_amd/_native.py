@@ -14,6 +14,7 @@ SPS_OK = 0
 ERR_RANGE = -4
 ERR_NOMEM = -3
 ERR_INVALID = -1
+ERR_ITEMCAP = -6
 
 
 class SpsError(RuntimeError):

@@ -1394,7 +1394,7 @@ static int report_device_errors(sps_ctx *c, int e, hipStream_t st) {
     return fail(SPS_ERR_INVALID, "train-mode BatchNorm: a level of the training forward had a single active row (Expected more "
                                  "than 1 value per channel when training)");
   if (e & 4)
-    return fail(SPS_ERR_NOMEM, "sps_radius_item: the item buffer is too small for the scan rows + the radius submap rows "
+    return fail(SPS_ERR_ITEMCAP, "sps_radius_item: the item buffer is too small for the scan rows + the radius submap rows "
                                "(the rows beyond it were dropped): pass a larger row_cap");
   return fail(SPS_ERR_RANGE,
               "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");

@@ -263,7 +263,7 @@ class DeviceItemLoader:
 
     def collate(self, idxs) -> torch.Tensor:
         """[sum N, 6] float32 device tensor = collate_fn([dataset[i] for i in idxs])."""
-        from .._native import ERR_NOMEM, SpsError
+        from .._native import ERR_ITEMCAP, SpsError
         arrs = [np.asarray(self.scans[i]) for i in idxs]
         f64 = arrs[0].dtype == np.float64
         tdt, esz = (torch.float64, 8) if f64 else (torch.float32, 4)
@@ -297,7 +297,7 @@ class DeviceItemLoader:
                     cx.check_errors(st.cuda_stream)
                     break
                 except SpsError as e:
-                    if e.code != ERR_NOMEM:
+                    if e.code != ERR_ITEMCAP:
                         raise
                     self.row_factor *= 2.0                         # denser map than the buffers were sized for
             batch = self._rows[: ends[-1]].clone()

@@ -20,7 +20,7 @@ import torch
 
 from .models.models import SPSNet, _require_device_tensor, get_context, metrics_from_sums
 
-DEFAULT_STREAMS = 23      # the HIP runtime multiplexes streams onto 4 hardware queues; 4k+3 maps best
+DEFAULT_STREAMS = 7       # knee of the stream sweep; the runtime multiplexes streams onto 4 hardware queues: 4k+3 maps best
 
 
 class ScanEngine:
@@ -182,6 +182,17 @@ class ScanEngine:
             for cx in self.ctxs[1:]:
                 cx.radius_grid_attach(self.ctxs[0])
 
+    def calibrate_rows(self, scans) -> float:
+        """Sets ``row_factor`` (item rows per scan point the buffers are sized for) from the radius query of a few sample
+        scans: 1.25 x the largest (n + m) / n seen (the submap keeps duplicates: a map at the network's voxel size gives
+        ~6 rows per scan point).  One-off, synchronises."""
+        worst = 1.0
+        for s in scans:
+            _, counts = self.submap.query(np.asarray(s)[:, :3])
+            worst = max(worst, 1.0 + float(counts.sum().item()) / max(len(s), 1))
+        self.row_factor = max(self.row_factor, 1.25 * worst)
+        return self.row_factor
+
     def prepare_scans(self, max_points: int, dtype=np.float64) -> None:
         """Raw-scan staging, item buffers and arenas of every stream sized for groups of up to ``max_points`` scan points
         (everything that is not steady state happens before the loop)."""
@@ -256,6 +267,10 @@ class ScanEngine:
                 o += a.shape[0]
             cx.forward_metrics_n(rows.data_ptr(), 6, rows.shape[0], nrows.data_ptr(), self.vs, self.eps, nb, scores.data_ptr(),
                                  self.table[row: row + nb].data_ptr(), st.cuda_stream)
+            ev = self._done[k]                      # marker behind the step (see submit())
+            if ev is None:
+                ev = self._done[k] = torch.cuda.Event()
+            ev.record(st)
         self.last_stream = st
         return scores
 

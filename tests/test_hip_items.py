@@ -87,7 +87,7 @@ def test_radius_item_equals_the_reference_item(dtype):
 
 
 def test_radius_item_overflow_is_reported():
-    from sps_amd._native import ERR_NOMEM, SpsError
+    from sps_amd._native import ERR_ITEMCAP, SpsError
     from sps_amd.datasets.blt_dataset import DeviceRadiusSubmap
     from sps_amd.models.models import get_context
     pc_map, scans = _scene()
@@ -104,7 +104,7 @@ def test_radius_item_overflow_is_reported():
     assert int(nrows[0]) == n + 10 and (guard == -7.0).all()
     with pytest.raises(SpsError) as e:
         cx.check_errors(st)
-    assert e.value.code == ERR_NOMEM and "item buffer" in str(e.value)
+    assert e.value.code == ERR_ITEMCAP and "item buffer" in str(e.value)
     cx.check_errors(st)                                             # the flag is cleared by the report
     del sub
 
@@ -141,14 +141,14 @@ def test_engine_submit_scans_matches_host_items(net):
     np.testing.assert_allclose(got[:, 6:], want[:, 6:], rtol=1e-12)   # sum g, sum g^2: labels only
     assert (got[:, 1] + got[:, 2] > 0).all() and (got[:, 3] + got[:, 4] > 0).all()
     # a group that outgrows the item buffers is reported at the sequence's one synchronisation
-    from sps_amd._native import ERR_NOMEM, SpsError
+    from sps_amd._native import ERR_ITEMCAP, SpsError
     eng.row_factor = 1.0
     eng._rows = [None] * len(eng.streams)
     eng.reset_table(8)
     eng.submit_scans([scans[0]])
     with pytest.raises(SpsError) as e:
         eng.finish()
-    assert e.value.code == ERR_NOMEM
+    assert e.value.code == ERR_ITEMCAP
 
 
 def _run(cmd, env_extra, timeout=900):
