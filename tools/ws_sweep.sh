@@ -9,7 +9,8 @@ for spec in "$@"; do
   export SPS_LIB=$lib
   env $envs timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-h2d 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read()); st=d['roofline']['stages']
-sel=[s for s in st if s['stage'][:6] in ('block2','block3','block4','block5','block6','conv3p','conv4p')]
-print('[$spec]', d['value'], 'scans/s | serial sum', d['roofline']['stage_ms_sum'], '| coarse', round(sum(s['ms'] for s in sel)*1000,1), '|', ' '.join(s['stage'].replace('block','b').replace('.0.conv','c').replace('conv','c')+':'+str(round(s['ms']*1000,1)) for s in sel), '| parity', (d.get('parity') or {}).get('max_abs_score_diff'))"
+import os; pre=tuple(os.environ.get('SWEEP_STAGES','block2,block3,block4,block5,block6,conv3p,conv4p').split(','))
+sel=[s for s in st if s['stage'].startswith(pre)]
+print('[$spec]', d['value'], 'scans/s | serial sum', d['roofline']['stage_ms_sum'], '| selected', round(sum(s['ms'] for s in sel)*1000,1), '|', ' '.join(s['stage'].replace('block','b').replace('.0.conv','c').replace('conv','c')+':'+str(round(s['ms']*1000,1)) for s in sel), '| parity', (d.get('parity') or {}).get('max_abs_score_diff'))"
   unset SPS_LIB; rm -f $lib
 done
