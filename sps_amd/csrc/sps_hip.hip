@@ -594,13 +594,13 @@ void launch_px(dim3 grid, hipStream_t st, const ConvArgs &a) {
 }
 
 // k_conv instantiation for a launch geometry (column tiles per wave x splits) -- shared by inference and training
-int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t st) {
+int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t st, unsigned lds_pad = 0) {
 #define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
   do {                                                                                            \
     if (ds)                                                                                       \
-      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(256), 0, st, a);     \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(256), lds_pad, st, a);     \
     else                                                                                          \
-      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(256), 0, st, a);    \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(256), lds_pad, st, a);    \
   } while (0)
   const int key = g.ntw * 10 + g.S;
   switch (key) {
@@ -783,7 +783,14 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
     return SPS_OK;
   }
-  return launch_k_conv(a, g, ds, grid, st);
+  unsigned lds_pad = 0;
+#if defined(SPS_DIAG)
+  {  // occupancy cap of the coarse-level launches (dynamic LDS that is never touched): SPS_CONV_LDS_PAD=<bytes>
+    static const int pad = [] { const char *e = diag_env("SPS_CONV_LDS_PAD"); return e ? atoi(e) : 0; }();
+    if (cc.level_out >= 2 && cs.K == 81) lds_pad = (unsigned)pad;
+  }
+#endif
+  return launch_k_conv(a, g, ds, grid, st, lds_pad);
 }
 
 // Host-side permutation of one kernel [K][cin][cout] into the unit-major MFMA B-fragment order
