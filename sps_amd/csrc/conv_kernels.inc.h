@@ -44,6 +44,8 @@ struct ConvArgs {
   int rb_supertiles;  // supertiles the rulebook arrays hold
   // k_conv_ws (coarse levels): slab of the slices' partial sums + one ticket per supertile; workgroups wanted per launch
   // and the largest slice count
+  const int *tile_order;   // k_conv: the level's tiles sorted by present-offset count, heaviest first (k_tile_order), or null
+  int order_ways;          // > 0: positions are laid out boustrophedon over tiers of this many (positions that share a CU)
   float *slab;
   int *ticket;
   uint32_t slab_bytes;
@@ -85,15 +87,16 @@ __device__ unsigned long long g_wave_trace[4 * 32768];
 #endif
 
 template <int NTW, int G, int MINW, bool DS, bool FIN, int S>
-__global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
+__global__ __launch_bounds__(S == 8 ? 512 : 256, MINW) void k_conv(ConvArgs a) {
 #if defined(SPS_WAVE_TRACE)
   const unsigned long long tr_t0 = wall_clock64();
   unsigned long long tr_t1 = 0;
   int tr_tiles = 0, tr_units = 0;
 #endif
-  __shared__ unsigned char klist[4][128];
-  __shared__ uint32_t aoff_s[4][KCHUNK * 16];
-  __shared__ uint32_t woff_s[4][KCHUNK];
+  constexpr int NWV = S == 8 ? 8 : 4;  // waves per workgroup (S = 8: one tile, eight splits, 512 threads)
+  __shared__ unsigned char klist[NWV][128];
+  __shared__ uint32_t aoff_s[NWV][KCHUNK * 16];
+  __shared__ uint32_t woff_s[NWV][KCHUNK];
   if (a.abort_flag && *a.abort_flag) return;
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
@@ -104,10 +107,10 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const int nt0 = blockIdx.x * NTW;
   // split-K inside the workgroup: its four waves are (4 / S) tiles x S splits of the tile's unit list; the
   // partial sums meet in LDS (fixed order -> deterministic), so there is no slab in HBM and no second launch
-  constexpr int tpw = 4 / S;                           // S = 1, 2 or 4; tiles per workgroup
+  constexpr int tpw = NWV / S;                         // S = 1, 2, 4 or 8; tiles per workgroup
   const int tl = S == 1 ? wave : wave / S;
   const int split = S == 1 ? 0 : wave - tl * S;
-  __shared__ float red_s[S > 1 ? 3 * NTW * 4 * 64 : 1];
+  __shared__ float red_s[S > 1 ? (NWV - tpw) * NTW * 4 * 64 : 1];
   unsigned char *kl = klist[wave];
   uint32_t *ao = aoff_s[wave];
   uint32_t *wo = woff_s[wave];
@@ -131,17 +134,29 @@ __global__ __launch_bounds__(256, MINW) void k_conv(ConvArgs a) {
   const float efw = (FIN && r < a.cout) ? a.fin_w[r] : 0.f;
   // the first tile's mask words do not depend on the row count: fetch them alongside it (saves a
   // dependent round trip; tile_cap = tiles the mask buffer was allocated for)
-  const int tile_first = blockIdx.y * tpw + tl;
+  const int pos_first = blockIdx.y * tpw + tl;
+  // (with a tile order the first mask needs the order entry first: one dependent load more, no prefetch)
+  const int tile_first = a.tile_order ? -1 : pos_first;
   uint32_t pw0 = 0u, pw1 = 0u;
-  if (a.tmask && tile_first < a.tile_cap) {
+  if (a.tmask && tile_first >= 0 && tile_first < a.tile_cap) {
     pw0 = a.tmask[(size_t)tile_first * 4 + (lane >> 5)];
     pw1 = a.tmask[(size_t)tile_first * 4 + 2 + (lane >> 5)];
   }
   // the loop bound is workgroup-uniform (the S > 1 path has barriers); a wave whose tile lies past the end
   // runs an empty unit list
   for (int grp = blockIdx.y; grp * tpw < ntiles; grp += gridDim.y) {
-    const int tile = grp * tpw + tl;
-    const bool active = tile < ntiles;
+    const int pos = grp * tpw + tl;
+    const bool active = pos < ntiles;
+    int tile = pos;
+    if (a.tile_order && active) {
+      int idx = pos;
+      if (a.order_ways > 0) {  // odd tiers run backwards (a last, partial tier is taken as is)
+        const int tier = pos / a.order_ways, c = pos - tier * a.order_ways;
+        const int len = min(a.order_ways, ntiles - tier * a.order_ways);
+        idx = tier * a.order_ways + ((tier & 1) ? len - 1 - c : c);
+      }
+      tile = a.tile_order[idx];
+    }
     if (S == 1 && !active) continue;
     const int row0 = tile * 16;
     // ---- prologue: compact list of present offsets (wave-synchronous LDS)
@@ -1037,8 +1052,12 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
 __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_out, LevelView L,
                                                       const float *__restrict__ W, const float *__restrict__ scale,
                                                       const float *__restrict__ shift, float in_const,
-                                                      float *__restrict__ out, int ldo, int relu) {
+                                                      float *__restrict__ out, int ldo, int relu, TileOrderArgs to, int g0) {
   __shared__ float w_s[128 * 8];
+  if ((int)blockIdx.x >= g0) {  // the workgroups behind the convolution's: balanced tile orders of the coarse levels
+    tile_order_body(to, (int)blockIdx.x - g0);
+    return;
+  }
   if (n_out[ABORT]) return;  // n_out = counts + 0
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
@@ -1047,7 +1066,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += g0 * 4) {
     const int row0 = tile * 16;
     const int u = row0 + r;
     uint32_t bm[4] = {0u, 0u, 0u, 0u};
@@ -1159,9 +1178,13 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
                                                      const float *__restrict__ W, const float *__restrict__ scale,
                                                      const float *__restrict__ shift,
                                                      const float *__restrict__ vfeat, float *__restrict__ out,
-                                                     int ldo) {
+                                                     int ldo, TileOrderArgs to, int g0) {
   __shared__ float w_s[128 * 8];
   __shared__ float val_s[4][16][132];  // row stride 132: lane (r, q) reads bank 4r + q (+ 4g): conflict-free
+  if ((int)blockIdx.x >= g0) {
+    tile_order_body(to, (int)blockIdx.x - g0);
+    return;
+  }
   if (n_out[ABORT]) return;  // n_out = counts + 0
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
@@ -1171,7 +1194,7 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
   float *va = val_s[wave][r];
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += g0 * 4) {
     const int row0 = tile * 16;
     const int u = row0 + r;
     __builtin_amdgcn_wave_barrier();

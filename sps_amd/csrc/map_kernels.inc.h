@@ -284,3 +284,54 @@ __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slic
   if ((threadIdx.x & 63) == 0 && c) atomicAdd(&pairs[k], (unsigned long long)c);
 }
 
+// ------------------------------------------------------------------------------------------
+// Balanced tile order for the output-stationary convolutions of the coarse levels (round 3).
+//   A k_conv workgroup = one 16-row tile (x column group); its work is proportional to the tile's present offsets
+//   (18 .. 54 at level 3) and the workgroups of a launch are all resident at once, dealt to the CUs in block-index order: a CU
+//   that happens to receive three 54-offset tiles takes twice as long as the average one, and that CU is the launch.
+//   tile_order_body (one workgroup per level) sorts the tiles of a level by their present-offset count (counting sort, 82
+//   buckets, heaviest first) and lays them out boustrophedon over tiers of TILE_ORDER_WAYS positions, so that the positions
+//   p, p + WAYS, p + 2 WAYS ... that round-robin dispatch gives to one CU hold one heavy, one light, one heavy ... tile.
+//   order[p] = tile of position p; the convolution results do not depend on it (a tile is computed the same wherever it runs).
+// ------------------------------------------------------------------------------------------
+#ifndef SPS_TILE_ORDER
+#define SPS_TILE_ORDER 2   // 0: natural order (no kernel), 1: heaviest first, 2: heaviest first, k_conv lays the positions out boustrophedon
+#endif
+#ifndef SPS_TILE_ORDER_WAYS
+#define SPS_TILE_ORDER_WAYS 256
+#endif
+constexpr int TILE_ORDER = SPS_TILE_ORDER, TILE_ORDER_WAYS = SPS_TILE_ORDER_WAYS;
+constexpr int TILE_ORDER_FIRST_LEVEL = 2;
+struct TileOrderArgs {
+  const uint32_t *tm3[NLV];
+  int *order[NLV];
+  const int *counts;
+};
+// (runs as the last workgroups of the conv0 launch, which follows k_maps and precedes every consumer: no launch of its own)
+__device__ inline void tile_order_body(const TileOrderArgs &a, int which) {
+  __shared__ int hist[88], start[88], cursor[88];
+  if (a.counts[ABORT]) return;
+  const int l = TILE_ORDER_FIRST_LEVEL + which;
+  const int nt = (a.counts[l] + 15) >> 4;
+  const uint32_t *__restrict__ tm = a.tm3[l];
+  if (threadIdx.x < 88) hist[threadIdx.x] = 0, cursor[threadIdx.x] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+    const int w = __popc(tm[(size_t)t * 4] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 1] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 2] & 0x7FFFFFFu);
+    atomicAdd(&hist[w], 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int s = 0;
+    for (int w = 81; w >= 0; --w) {  // heaviest first
+      start[w] = s;
+      s += hist[w];
+    }
+  }
+  __syncthreads();
+  int *__restrict__ sorted = a.order[l];
+  for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+    const int w = __popc(tm[(size_t)t * 4] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 1] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 2] & 0x7FFFFFFu);
+    sorted[start[w] + atomicAdd(&cursor[w], 1)] = t;  // (the order inside a bucket varies from run to run: scheduling only)
+  }
+}

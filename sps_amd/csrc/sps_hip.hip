@@ -165,6 +165,7 @@ struct Level {
   int *nbr3 = nullptr;         // [81][cap]
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
   uint32_t *tm3 = nullptr, *tmdown = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
+  int *tile_order = nullptr;  // [cap/16] the level's tiles sorted by present-offset count (conv0 launch; read by k_conv)
   // rulebook of the 3x3x3x3 map (levels that run k_conv_px): per supertile of 64 rows
   uint32_t *rb_e = nullptr;       // [cap/64][PX_CH_MAX][16] pair entries
   unsigned char *rb_k = nullptr;  // [cap/64][PX_KSTRIDE] offset of each chunk
@@ -397,6 +398,8 @@ int reserve(sps_ctx *c, int64_t n) {
       if (l > 0) {
         ALLOC(L.down, int, 8 * rows);
       }
+      L.tile_order = nullptr;
+      if (TILE_ORDER != 0 && l >= TILE_ORDER_FIRST_LEVEL) ALLOC(L.tile_order, int, rows / 16);
       // never-written entries must still be valid indices (stale reads in an aborted forward stay in range)
       HIP_TRY(hipMemset(L.vblock, 0, sizeof(int) * (size_t)rows));
       HIP_TRY(hipMemset(L.vbit, 0, (size_t)rows));
@@ -578,7 +581,7 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
       snprintf(name, sizeof name, "SPS_GEOM_L%d", l);
       const char *e = diag_env(name);
       int ntw = 1, S = 1;
-      if (e && sscanf(e, "%d,%d", &ntw, &S) == 2 && (S == 1 || S == 2 || S == 4) && (ntw == 1 || ntw == 2 || ntw == 4))
+      if (e && sscanf(e, "%d,%d", &ntw, &S) == 2 && (S == 1 || S == 2 || S == 4 || S == 8) && (ntw == 1 || ntw == 2 || ntw == 4))
         h[l] = Hook{true, ntw, S};
     }
     return h;
@@ -598,9 +601,9 @@ int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t
 #define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
   do {                                                                                            \
     if (ds)                                                                                       \
-      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(256), lds_pad, st, a);     \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, S_>), grid, dim3(S_ == 8 ? 512 : 256), lds_pad, st, a);     \
     else                                                                                          \
-      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(256), lds_pad, st, a);    \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(S_ == 8 ? 512 : 256), lds_pad, st, a);    \
   } while (0)
   const int key = g.ntw * 10 + g.S;
   switch (key) {
@@ -610,6 +613,8 @@ int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t
     case 21: SPS_LAUNCH(2, SPS_G2, SPS_W2, 1); break;
     case 22: SPS_LAUNCH(2, SPS_G2, SPS_W2, 2); break;
     case 24: SPS_LAUNCH(2, SPS_G2, SPS_W2, 4); break;
+    case 18: SPS_LAUNCH(1, SPS_G1, 3, 8); break;
+    case 28: SPS_LAUNCH(2, SPS_G2, 3, 8); break;
     case 41: SPS_LAUNCH(4, SPS_G4, SPS_W4, 1); break;
     case 42: SPS_LAUNCH(4, SPS_G4, SPS_W4, 2); break;
     case 44: SPS_LAUNCH(4, SPS_G4, SPS_W4, 4); break;
@@ -679,18 +684,32 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
   a.nbr_bytes = (uint32_t)((size_t)cs.K * (size_t)c->capl[cc.level_out] * 4u);
   a.tile_cap = (int)(c->capl[cc.level_out] / 16);
+  // 3x3x3x3 layers of the coarse levels: tiles in the level's balanced order
+  a.tile_order = (TILE_ORDER != 0 && cs.K == 81 && cc.level_out >= TILE_ORDER_FIRST_LEVEL) ? c->lv[cc.level_out].tile_order : nullptr;
+  // workgroups are dealt to the CUs in block-index order (column group fastest): positions p and p + 256 / column groups share a CU
+  a.order_ways = TILE_ORDER == 2 ? TILE_ORDER_WAYS / std::max(1, a.NT / g.ntw) : 0;
   {
     static const char *trace_layer = diag_env("SPS_TRACE_LAYER");  // diagnostic builds (-DSPS_WAVE_TRACE) only
     a.trace_on = trace_layer && std::strcmp(trace_layer, cc.name) == 0;
   }
   if (cs.cin == 1) {  // conv0p1s1: fused with its kernel map, no neighbour table
+    // its launch follows k_maps and precedes every 3x3x3x3 layer of the coarse levels: the last workgroups sort those
+    // levels' tiles by present-offset count (balanced tile order, map_kernels.inc.h) -- no launch of their own
+    TileOrderArgs to{};
+    const int g0 = grid_for(c->cap, 64, 4096);
+    int gto = 0;
+    if (TILE_ORDER != 0) {
+      for (int l = 0; l < NLV; ++l) to.tm3[l] = c->lv[l].tm3, to.order[l] = c->lv[l].tile_order;
+      to.counts = c->counts;
+      gto = NLV - TILE_ORDER_FIRST_LEVEL;
+    }
     if (c->cur_vfeat) {
-      hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
-                         c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, c->cur_vfeat, a.out, a.ldo);
+      hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)(g0 + gto)), dim3(256), 0, st, a.n_out,
+                         c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, c->cur_vfeat, a.out, a.ldo, to, g0);
       return SPS_OK;
     }
-    hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, a.n_out,
-                       c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo, 1);
+    hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)(g0 + gto)), dim3(256), 0, st, a.n_out,
+                       c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, a.in_const, a.out, a.ldo, 1, to, g0);
     return SPS_OK;
   }
   if (cs.K == 8 && std::strncmp(cc.name, "convtr", 6) == 0) {

@@ -426,8 +426,9 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
     const int lo = op.out.level;
     float *z = t->z[ci];
     if (op.kind == T_CONV0) {
-      hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)grid_for(c->cap, 64, 4096)), dim3(256), 0, st, c->counts + 0, c->lv[0].view(),
-                         t->blob + cs.w_off, t->ones, t->zeros, 0.5f, z, 8, 0);
+      const int g0 = grid_for(c->cap, 64, 4096);
+      hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)g0), dim3(256), 0, st, c->counts + 0, c->lv[0].view(),
+                         t->blob + cs.w_off, t->ones, t->zeros, 0.5f, z, 8, 0, TileOrderArgs{}, g0);
     } else if (op.kind == T_UP) {
       rc = conv_plain(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
     } else {

@@ -10,6 +10,8 @@ net = bench.synthetic_weights(SPSNet(bench.CFG)).to(dev).eval().freeze()
 b = synthetic.make_scene(scan_seed=1)["batch"]
 pinned = [torch.from_numpy(b).pin_memory() for _ in range(4)]
 K = 300
+import platform, os
+print('host', platform.node(), 'cpus', os.cpu_count(), 'affinity', len(os.sched_getaffinity(0)))
 for S in (7,):
     eng = ScanEngine(net, dev, streams=S, max_rows=len(b), table_rows=K, stage_cols=6)
     T = {}
@@ -18,9 +20,13 @@ for S in (7,):
             t = time.perf_counter(); r = fn(*a, **k); T[name] = T.get(name, 0.0) + time.perf_counter() - t; return r
         return w
     eng._to_device = timed("to_device", eng._to_device)
-    eng._flush = timed("flush", eng._flush)
-    ev_sync = torch.cuda.Event.synchronize
+    ev_sync, ev_rec = torch.cuda.Event.synchronize, torch.cuda.Event.record
     torch.cuda.Event.synchronize = timed("event.synchronize", ev_sync)
+    torch.cuda.Event.record = timed("event.record", ev_rec)
+    tcopy = torch.Tensor.copy_
+    torch.Tensor.copy_ = timed("copy_", tcopy)
+    tpin = torch.Tensor.is_pinned
+    torch.Tensor.is_pinned = timed("is_pinned", tpin)
     fm = net.forward_metrics
     net.forward_metrics = timed("forward_metrics", fm)
     for rep in range(2):
@@ -30,11 +36,10 @@ for S in (7,):
         t0 = time.perf_counter()
         for i in range(K):
             eng.submit(pinned[i % 4], 1, row=i)
-        eng.flush()
         issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         tot = time.perf_counter() - t0
         eng.finish()
         print(f"S={S} rep {rep}: issue {issue/K*1e3:.3f} ms/step total {tot/K*1e3:.3f} ms/step -> {K/tot:.0f} scans/s | " +
               " ".join(f"{k} {v/K*1e3:.3f}" for k, v in T.items()))
-    torch.cuda.Event.synchronize = ev_sync
+    torch.cuda.Event.synchronize = ev_sync; torch.cuda.Event.record = ev_rec; torch.Tensor.copy_ = tcopy; torch.Tensor.is_pinned = tpin
