@@ -44,6 +44,7 @@ struct ConvArgs {
   int rb_supertiles;  // supertiles the rulebook arrays hold
   // k_conv_ws (coarse levels): slab of the slices' partial sums + one ticket per supertile; workgroups wanted per launch
   // and the largest slice count
+  const int4 *px_order;    // k_conv_px: position -> {supertile, chunks of its three slices}, balanced order (px_order_body), or null
   const int *tile_order;   // k_conv: the level's tiles sorted by present-offset count, heaviest first (k_tile_order), or null
   int order_ways;          // > 0: positions are laid out boustrophedon over tiers of this many (positions that share a CU)
   float *slab;
@@ -443,9 +444,17 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   PX_STAMP(0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = lane & 15, q = lane >> 4;
-  // the first supertile's chunk counts do not depend on the row count: fetch them alongside (one round trip less)
-  int4 nseg_first = make_int4(0, 0, 0, 0);
-  if ((int)blockIdx.x < a.rb_supertiles) nseg_first = *reinterpret_cast<const int4 *>(a.rb_cnt + (size_t)blockIdx.x * 4);
+  // the first supertile's entry does not depend on the row count: fetch it alongside (one round trip less).  With a balanced
+  // order (a.px_order: {supertile, chunks per slice} by position) the position's supertile comes with its chunk counts.
+  int4 ent_first = make_int4((int)blockIdx.x, 0, 0, 0);
+  if ((int)blockIdx.x < a.rb_supertiles) {
+    if (a.px_order) {
+      ent_first = a.px_order[blockIdx.x];
+    } else {
+      const int4 ns = *reinterpret_cast<const int4 *>(a.rb_cnt + (size_t)blockIdx.x * 4);
+      ent_first = make_int4((int)blockIdx.x, ns.x, ns.y, ns.z);
+    }
+  }
   const int aborted = a.abort_flag ? *a.abort_flag : 0;
   const int count = *a.n_out;
   if (aborted) return;
@@ -466,11 +475,20 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   float *acc = acc_s[wave];
   const bool rmw = !C8 || q < 2;  // C_out <= 8: lane groups 2, 3 hold the zero-padded channels 8..15
 
-  for (int st = blockIdx.x; st < nst; st += gridDim.x) {
+  for (int pos = blockIdx.x; pos < nst; pos += gridDim.x) {
+    int4 ent = ent_first;
+    if (pos != (int)blockIdx.x) {
+      if (a.px_order) {
+        ent = a.px_order[pos];
+      } else {
+        const int4 ns = *reinterpret_cast<const int4 *>(a.rb_cnt + (size_t)pos * 4);
+        ent = make_int4(pos, ns.x, ns.y, ns.z);
+      }
+    }
+    const int st = min(max(ent.x, 0), nst - 1);  // (an entry is always a valid supertile; clamped against stale memory)
     const int row0 = st * 64;
-    const int4 nseg = st == (int)blockIdx.x ? nseg_first : *reinterpret_cast<const int4 *>(a.rb_cnt + (size_t)st * 4);
-    const int n0 = nseg.x, n01 = nseg.x + nseg.y;
-    const int nch = n01 + nseg.z;  // chunk c lives in segment 0 (c < n0), 1 (c < n01) or 2
+    const int n0 = ent.y, n01 = ent.y + ent.z;
+    const int nch = n01 + ent.w;  // chunk c lives in segment 0 (c < n0), 1 (c < n01) or 2
     const __amdgpu_buffer_rsrc_t rsE =
         __builtin_amdgcn_make_buffer_rsrc((void *)(a.rb_e + (size_t)st * (PX_CH_MAX * 16)), 0, PX_CH_MAX * 64, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsK =
@@ -1054,10 +1072,18 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
                                                       const float *__restrict__ shift, float in_const,
                                                       float *__restrict__ out, int ldo, int relu, TileOrderArgs to, int g0) {
   __shared__ float w_s[128 * 8];
-  if ((int)blockIdx.x >= g0) {  // the workgroups behind the convolution's: balanced tile orders of the coarse levels
-    tile_order_body(to, (int)blockIdx.x - g0);
+  // the FIRST workgroups of the launch (they start at once; three dependent passes each): balanced tile orders of the other
+  // layers' launches; the convolution's own workgroups follow
+  const int gto = (int)gridDim.x - g0;
+  if ((int)blockIdx.x < gto) {
+    const int which = (int)blockIdx.x;
+    if (which < NLV - TILE_ORDER_FIRST_LEVEL)
+      tile_order_body(to, which);
+    else
+      px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
     return;
   }
+  const int bid = (int)blockIdx.x - gto;
   if (n_out[ABORT]) return;  // n_out = counts + 0
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
@@ -1066,7 +1092,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += g0 * 4) {
+  for (int tile = bid * 4 + wave; tile < ntiles; tile += g0 * 4) {
     const int row0 = tile * 16;
     const int u = row0 + r;
     uint32_t bm[4] = {0u, 0u, 0u, 0u};
@@ -1181,10 +1207,16 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
                                                      int ldo, TileOrderArgs to, int g0) {
   __shared__ float w_s[128 * 8];
   __shared__ float val_s[4][16][132];  // row stride 132: lane (r, q) reads bank 4r + q (+ 4g): conflict-free
-  if ((int)blockIdx.x >= g0) {
-    tile_order_body(to, (int)blockIdx.x - g0);
+  const int gto = (int)gridDim.x - g0;
+  if ((int)blockIdx.x < gto) {
+    const int which = (int)blockIdx.x;
+    if (which < NLV - TILE_ORDER_FIRST_LEVEL)
+      tile_order_body(to, which);
+    else
+      px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
     return;
   }
+  const int bid = (int)blockIdx.x - gto;
   if (n_out[ABORT]) return;  // n_out = counts + 0
   for (int i = threadIdx.x; i < 128 * 8; i += blockDim.x) w_s[i] = i < 125 * 8 ? W[i] : 0.f;
   __syncthreads();
@@ -1194,7 +1226,7 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
   float *va = val_s[wave][r];
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += g0 * 4) {
+  for (int tile = bid * 4 + wave; tile < ntiles; tile += g0 * 4) {
     const int row0 = tile * 16;
     const int u = row0 + r;
     __builtin_amdgcn_wave_barrier();

@@ -306,7 +306,37 @@ struct TileOrderArgs {
   const uint32_t *tm3[NLV];
   int *order[NLV];
   const int *counts;
+  // pair-exact levels: supertiles by chunk count (k_conv_px reads {supertile, chunks per slice} at its position)
+  const int *rb_cnt[NLV];
+  int *px_sorted[NLV];
+  int4 *px_order[NLV];
 };
+// start[w] = number of elements in buckets heavier than w (heaviest first), for nb <= 384 buckets: one wave, six buckets per lane
+__device__ inline void bucket_starts_desc(const int *hist, int *start, int nb) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
+    int loc[6], tot = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int w = nb - 1 - (lane * 6 + j);  // lane 0 holds the heaviest buckets
+      loc[j] = w >= 0 ? hist[w] : 0;
+      tot += loc[j];
+    }
+    int inc = tot;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int y = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += y;
+    }
+    int run = inc - tot;  // elements in the lanes before this one
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int w = nb - 1 - (lane * 6 + j);
+      if (w >= 0) start[w] = run;
+      run += loc[j];
+    }
+  }
+}
+
 // (runs as the last workgroups of the conv0 launch, which follows k_maps and precedes every consumer: no launch of its own)
 __device__ inline void tile_order_body(const TileOrderArgs &a, int which) {
   __shared__ int hist[88], start[88], cursor[88];
@@ -321,17 +351,46 @@ __device__ inline void tile_order_body(const TileOrderArgs &a, int which) {
     atomicAdd(&hist[w], 1);
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int s = 0;
-    for (int w = 81; w >= 0; --w) {  // heaviest first
-      start[w] = s;
-      s += hist[w];
-    }
-  }
+  bucket_starts_desc(hist, start, 82);  // heaviest first
   __syncthreads();
   int *__restrict__ sorted = a.order[l];
   for (int t = threadIdx.x; t < nt; t += blockDim.x) {
     const int w = __popc(tm[(size_t)t * 4] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 1] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 2] & 0x7FFFFFFu);
     sorted[start[w] + atomicAdd(&cursor[w], 1)] = t;  // (the order inside a bucket varies from run to run: scheduling only)
+  }
+}
+
+// The same for the pair-exact convolutions of levels 0-1 (`which` = NLV - TILE_ORDER_FIRST_LEVEL + level): a k_conv_px
+// workgroup = one 64-row supertile, its work = its chunk count (51 / 88 / 138 at p10 / p50 / p90 of level 0); the 1-D grid lands
+// workgroup b on CU b mod 256.  px_order[p] = {supertile, chunks of its three time slices} in position order (heaviest first,
+// boustrophedon over tiers of 256): the convolution finds everything it used to prefetch from rb_cnt in one 16-byte load.
+constexpr int PX_ORDER_WAYS = 256;
+__device__ inline void px_order_body(const TileOrderArgs &a, int l) {
+  __shared__ int hist[PX_CH_MAX + 4], start[PX_CH_MAX + 4];
+  if (a.counts[ABORT] || !a.rb_cnt[l]) return;
+  const int nst = (a.counts[l] + 63) >> 6;
+  const int *__restrict__ rbc = a.rb_cnt[l];
+  for (int i = threadIdx.x; i < PX_CH_MAX + 4; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  const int4 *__restrict__ rbc4 = reinterpret_cast<const int4 *>(rbc);
+  for (int t = threadIdx.x; t < nst; t += blockDim.x) {
+    const int4 ns = rbc4[t];
+    atomicAdd(&hist[min(PX_CH_MAX, ns.x + ns.y + ns.z)], 1);
+  }
+  __syncthreads();
+  bucket_starts_desc(hist, start, PX_CH_MAX + 1);  // heaviest first
+  __syncthreads();
+  int *sorted = a.px_sorted[l];
+  for (int t = threadIdx.x; t < nst; t += blockDim.x) {
+    const int4 ns = rbc4[t];
+    __hip_atomic_store(sorted + atomicAdd(&start[min(PX_CH_MAX, ns.x + ns.y + ns.z)], 1), t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  for (int p = threadIdx.x; p < nst; p += blockDim.x) {
+    const int tier = p / PX_ORDER_WAYS, c = p - tier * PX_ORDER_WAYS;
+    const int len = min(PX_ORDER_WAYS, nst - tier * PX_ORDER_WAYS);
+    const int st = __hip_atomic_load(sorted + tier * PX_ORDER_WAYS + ((tier & 1) ? len - 1 - c : c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int4 ns = rbc4[st];
+    a.px_order[l][p] = make_int4(st, ns.x, ns.y, ns.z);
   }
 }

@@ -166,6 +166,8 @@ struct Level {
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
   uint32_t *tm3 = nullptr, *tmdown = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
   int *tile_order = nullptr;  // [cap/16] the level's tiles sorted by present-offset count (conv0 launch; read by k_conv)
+  int *px_sorted = nullptr;   // [cap/64] pair-exact levels: supertiles sorted by chunk count
+  int4 *px_order = nullptr;   // [cap/64] position -> {supertile, chunks per slice} (conv0 launch; read by k_conv_px)
   // rulebook of the 3x3x3x3 map (levels that run k_conv_px): per supertile of 64 rows
   uint32_t *rb_e = nullptr;       // [cap/64][PX_CH_MAX][16] pair entries
   unsigned char *rb_k = nullptr;  // [cap/64][PX_KSTRIDE] offset of each chunk
@@ -394,6 +396,12 @@ int reserve(sps_ctx *c, int64_t n) {
         }
         ALLOC(L.rb_k, unsigned char, (rows / 64) * (int64_t)PX_KSTRIDE);
         ALLOC(L.rb_cnt, int, (rows / 64) * 4);
+        L.px_sorted = nullptr, L.px_order = nullptr;
+        if (TILE_ORDER != 0) {
+          ALLOC(L.px_sorted, int, rows / 64);
+          ALLOC(L.px_order, int4, rows / 64);
+          HIP_TRY(hipMemset(L.px_order, 0, sizeof(int4) * (size_t)(rows / 64)));
+        }
       }
       if (l > 0) {
         ALLOC(L.down, int, 8 * rows);
@@ -699,9 +707,13 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     const int g0 = grid_for(c->cap, 64, 4096);
     int gto = 0;
     if (TILE_ORDER != 0) {
-      for (int l = 0; l < NLV; ++l) to.tm3[l] = c->lv[l].tm3, to.order[l] = c->lv[l].tile_order;
+      for (int l = 0; l < NLV; ++l) {
+        to.tm3[l] = c->lv[l].tm3, to.order[l] = c->lv[l].tile_order;
+        const bool px = l < PX_LEVELS && ((px_levels() >> l) & 1) && c->lv[l].px_order;
+        to.rb_cnt[l] = px ? c->lv[l].rb_cnt : nullptr, to.px_sorted[l] = c->lv[l].px_sorted, to.px_order[l] = c->lv[l].px_order;
+      }
       to.counts = c->counts;
-      gto = NLV - TILE_ORDER_FIRST_LEVEL;
+      gto = NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS;
     }
     if (c->cur_vfeat) {
       hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)(g0 + gto)), dim3(256), 0, st, a.n_out,
@@ -746,6 +758,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     a.rb_e = c->lv[cc.level_out].rb_e;
     a.rb_k = c->lv[cc.level_out].rb_k;
     a.rb_cnt = c->lv[cc.level_out].rb_cnt;
+    a.px_order = TILE_ORDER != 0 ? c->lv[cc.level_out].px_order : nullptr;
     a.rb_supertiles = (int)(c->capl[cc.level_out] / 64);
     const int key = cs.cin * 100 + (cs.cout == 8 ? 10 : 0) + (cc.fin ? 2 : (ds ? 1 : 0));
 #define SPS_PX_LAUNCH(CIN_, C8_, DS_, FIN_)                                                                  \
