@@ -176,6 +176,8 @@ def main():
         local = local % max(torch.cuda.device_count(), 1)      # debug: several ranks may share one GPU
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from sps_amd import hostplace
+    placement = hostplace.bind_to_gpu_numa(local)      # before the first pinned allocation
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
@@ -431,7 +433,7 @@ def main():
                    "compact_arenas": eng.compact},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,
         "mean_confusion": confusion, "inputs": inputs, "resident_inputs": resident, "h2d_inclusive": h2d,
-        "host_cores": os.cpu_count(),
+        "host_cores": os.cpu_count(), "host_placement": placement,
         "host_issue_ms_per_step": round(host_issue_ms, 4),
     }
     print(json.dumps(out))

@@ -82,6 +82,8 @@ def main(weights, sequence, config, n_synth, batch_size, streams, timing, force_
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    from sps_amd import hostplace
+    hostplace.bind_to_gpu_numa(local)          # CPUs (and pinned buffers) of the GPU's own NUMA node
     use_dist = world > 1 or force_dist
     if use_dist:
         import torch.distributed as dist

@@ -59,6 +59,8 @@ def main(config, n_synth, max_epochs, out, host_items):
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    from sps_amd import hostplace
+    hostplace.bind_to_gpu_numa(local)          # CPUs (and pinned buffers) of the GPU's own NUMA node
     if world > 1:
         # data-parallel over the GPUs of one node: batch i -> rank i mod W, identical initial weights (same seed), the
         # flat gradient averaged by ONE all-reduce per step (RCCL over xGMI; sps_amd/models/models.py::_TrainForward)
