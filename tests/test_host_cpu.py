@@ -278,3 +278,11 @@ def test_product_library_has_no_diagnostic_switches():
     assert not re.search(rb"SPS_[A-Z][A-Z_0-9]{3,}", blob), re.findall(rb"SPS_[A-Z][A-Z_0-9]{3,}", blob)[:5]
     syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
     assert "getenv" not in syms
+
+
+def test_hostplace_parses_cpulists_and_never_raises():
+    from sps_amd import hostplace
+    assert hostplace._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    assert hostplace._parse_cpulist("") == set()
+    info = hostplace.bind_to_gpu_numa(0)            # no GPU / no sysfs entry here: a note, not an exception
+    assert info["bound"] is False and set(info) >= {"pci", "numa_node", "cpus_before", "cpus_after", "bound"}
