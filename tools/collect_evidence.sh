@@ -29,6 +29,7 @@ python3 tools/pmc_derive.py $o/pmc_conv_layers.txt > $o/pmc_conv_layers_derived.
 python3 tools/train_timing.py --steps 50 2>> $o/bench.err | tail -1 > $o/train_timing.txt
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_train -- python3 tools/train_timing.py --steps 20 > /dev/null 2>> $o/bench.err
 cp $(ls $o/prof_train/*/*kernel_stats.csv | head -1) $o/kernel_stats_train.csv
+python3 tools/train_roofline.py $o/kernel_stats_train.csv $o/bench.json >> $o/train_timing.txt 2>> $o/bench.err
 python3 tools/filter_timing.py 2>> $o/bench.err | tail -4 > $o/filter_timing.txt
 rm -rf $o/prof_train $o/prof_serial $o/prof_pipelined $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/pmc_a $o/pmc_b
 ls -la $o; tail -3 $o/bench.err; cat $o/train_timing.txt $o/filter_timing.txt; cat $o/traffic_summary.txt; cat $o/pmc_conv_layers_derived.txt | head -30
