@@ -150,6 +150,9 @@ def main(config, n_synth, max_epochs, out, host_items):
                 vl.append(v["val_loss"])
                 vr.append(v["val_r2"])
         scheduler.step()
+        # sticky device errors of the epoch's forwards (coordinate range, a level with a single row under train-mode BatchNorm)
+        # surface here: one synchronisation per epoch, not per step
+        models.get_context(dev.index or 0, torch.cuda.current_stream().cuda_stream).check_errors(torch.cuda.current_stream().cuda_stream)
         if world > 1 and sharded:                       # every rank validated its own part of the split: pool the sums
             t = torch.tensor([float(torch.stack(vl).sum()) if vl else 0.0, float(torch.stack(vr).sum()) if vr else 0.0,
                               float(len(vl))], dtype=torch.float64, device=dev)
