@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_points_to_blocks(const float *__restric
 struct PyramidArgs {
   BHash h[NLV];
   int *sslot[NLV];    // [l] hash slot (level l) of each SOURCE: points for l = 0, level-0 blocks for l >= 1
+  const unsigned char *sbit0;  // bit of every point inside its level-0 block
   int *bslot[NLV];
   uint64_t *bkey[NLV];
   unsigned long long *bmask[NLV];
@@ -151,54 +152,17 @@ struct PyramidArgs {
   int *vblock[NLV];
   unsigned char *vbit[NLV];
   int *counts;        // [0..4] voxels per level, [8..12] blocks per level
-  int *block_sums;    // scan scratch, `sums_stride` ints per level
-  int sums_stride;
+  unsigned long long *agg;  // single-pass scan: packed (generation, blocks, voxels) of every logical workgroup, `agg_stride` per level
+  int agg_stride;
+  uint32_t gen;       // generation tag of this forward (never 0): an aggregate of another forward does not match
   const int *n_dev;   // null, or the device-side point count (<= the host-side bound the grids were sized for)
   int capl[NLV], bcapl[NLV];  // row / block capacity of every level (compact arenas: smaller than the point capacity)
-  int *err;           // sticky error flags of the context: bit 0 coordinate range, bit 1 level capacity exceeded
+  int *err;           // sticky error flags of the context: bit 0 coordinate range, bit 1 level capacity exceeded, bit 4 ranking wait timed out
 };
 
 // counts[ABORT]: set by the ranking kernels when a level needs more rows or blocks than its arrays hold; every later
 // kernel of the forward returns at once, the tail writes NaN scores and wipes the block hashes (sps_ctx compact mode)
 constexpr int ABORT = 15;
-
-// levels 1..4 in one pass: one thread per LEVEL-0 block inserts its ancestor block at every coarser
-// level (App. A.9: floor(c / 2ts) * 2ts applied l times = a right shift of the biased coordinate).
-// A level-0 block covers 2x2x2 level-1 voxels (an octant of its parent block) and exactly one voxel
-// of levels 2..4.
-__device__ inline void blocks_to_ancestors(const PyramidArgs &a, int l, int bx, int nbx) {
-  const int n = a.counts[8];
-  const int nround = (n + 255) & ~255;  // whole waves enter wave_run_insert
-  for (int r = bx * 256 + (int)threadIdx.x; r < nround; r += nbx * 256) {
-    const bool ok = r < n;
-    uint64_t pkey = KEY_EMPTY;
-    unsigned long long pm = 0;
-    if (ok) {
-      const uint64_t key = a.bkey[0][r];
-      const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF),
-                     bz = (uint32_t)((key >> 36) & 0x3FFFF);
-      const uint64_t bt = key & (0x3FFull << 54);
-      pkey = bt | ((uint64_t)(bz >> l) << 36) | ((uint64_t)(by >> l) << 18) | (uint64_t)(bx >> l);
-      if (l == 1) {
-        const unsigned long long m = a.bmask[0][r];
-        const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
-#pragma unroll
-        for (int k = 0; k < 2; ++k)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-              if (m & (0x0000000000330033ull << (2 * i + 8 * j + 32 * k)))
-                pm |= 1ull << ((2 * oz + k) * 16 + (2 * oy + j) * 4 + (2 * ox + i));
-      } else {
-        const uint32_t px = (bx >> (l - 2)) & 3, py = (by >> (l - 2)) & 3, pz = (bz >> (l - 2)) & 3;
-        pm = 1ull << ((pz << 4) | (py << 2) | px);
-      }
-    }
-    const int sl = wave_run_insert(a.h[l], pkey, ok, (uint32_t)pm, (uint32_t)(pm >> 32), r);
-    if (ok) a.sslot[l][r] = sl;
-  }
-}
 
 __device__ inline int block_reduce_sum(int v, int *lds) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -212,16 +176,45 @@ __device__ inline int block_reduce_sum(int v, int *lds) {
   return tot;
 }
 
-// exclusive scan of the pair (v0, v1) over the grid's elements given the per-workgroup totals
-// (block_sums[2*i], block_sums[2*i+1]) of an earlier pass: returns this thread's two offsets.
-__device__ inline int2 block_exclusive_scan2(int v0, int v1, const int *__restrict__ block_sums, int *lds, int2 *wave_off) {
+// counters behind the 16 level counters (all cleared by the first kernel of the forward):
+//   counts[TICKET + l]  logical workgroup ids of level l's ranking pass, handed out in the order the workgroups START
+//   counts[TOCC]        bit t set = some block has biased time index t (the time axis is never strided: valid at every level)
+constexpr int TICKET = 16, TOCC = 24, N_COUNTERS = 32;
+
+// ---- single-pass ranking ------------------------------------------------------------------------------------------------
+// Sources of level 0 are the points, of levels >= 1 the level-0 blocks.  A source is the FIRST of its block when
+// first[slot] == source index; the block's occupancy mask is already final, so block ranks and voxel row bases are scanned
+// together, in ONE launch per pass: a workgroup takes its logical id from a ticket, publishes the pair (first occurrences,
+// voxels) of its SCAN_BLOCK sources as one 64-bit word tagged with the forward's generation, and sums the words of ids
+// below its own.  Ids are handed out in start order, so every workgroup that is waited for is already running and waits
+// only on smaller ids: the spin ends whatever order the hardware dispatches in and whatever else shares the CUs.
+// word = generation << 32 | voxels (<= 4 * 1024 * 64: 19 bits) << 13 | first occurrences (<= 4 * 1024: 13 bits)
+__device__ inline unsigned long long agg_pack(uint32_t gen, int t0, int t1) {
+  return ((unsigned long long)gen << 32) | ((unsigned long long)(uint32_t)t1 << 13) | (unsigned long long)(uint32_t)t0;
+}
+constexpr int SCAN_SPIN_MAX = 1 << 22;  // (seconds; a wait that long means a broken invariant: flag it instead of hanging the GPU)
+__device__ inline int2 scan_lookback(const unsigned long long *agg, int id, uint32_t gen, int *lds, int *err) {
   int p0 = 0, p1 = 0;
-  for (int i = threadIdx.x; i < (int)blockIdx.x; i += SCAN_BLOCK) {
-    p0 += block_sums[2 * i];
-    p1 += block_sums[2 * i + 1];
+  for (int i = threadIdx.x; i < id; i += SCAN_BLOCK) {
+    unsigned long long v = __hip_atomic_load(agg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; (uint32_t)(v >> 32) != gen; ++spin) {
+      if (spin == SCAN_SPIN_MAX) {
+        atomicOr(err, 16);
+        v = 0ull;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+      v = __hip_atomic_load(agg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    p0 += (int)(v & 0x1FFFull);
+    p1 += (int)((v >> 13) & 0x7FFFFull);
   }
-  const int base0 = block_reduce_sum(p0, lds);
-  const int base1 = block_reduce_sum(p1, lds);
+  const int b0 = block_reduce_sum(p0, lds);
+  const int b1 = block_reduce_sum(p1, lds);
+  return make_int2(b0, b1);
+}
+// exclusive scan of the pair (v0, v1) inside the workgroup; tot = the workgroup's sums
+__device__ inline int2 block_exclusive_scan2(int v0, int v1, int2 *wave_off, int2 &tot) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int i0 = v0, i1 = v1;
   for (int o = 1; o < 64; o <<= 1) {
@@ -233,111 +226,220 @@ __device__ inline int2 block_exclusive_scan2(int v0, int v1, const int *__restri
   }
   if (lane == 63) wave_off[wave] = make_int2(i0, i1);
   __syncthreads();
-  int o0 = 0, o1 = 0;
-  for (int i = 0; i < wave; ++i) {
-    o0 += wave_off[i].x;
-    o1 += wave_off[i].y;
+  int o0 = 0, o1 = 0, s0 = 0, s1 = 0;
+  for (int i = 0; i < SCAN_BLOCK / 64; ++i) {
+    const int2 w = wave_off[i];
+    if (i < wave) o0 += w.x, o1 += w.y;
+    s0 += w.x, s1 += w.y;
   }
   __syncthreads();
-  return make_int2(base0 + o0 + i0 - v0, base1 + o1 + i1 - v1);
+  tot = make_int2(s0, s1);
+  return make_int2(o0 + i0 - v0, o1 + i1 - v1);
 }
 
-// Batched over levels lv0 + blockIdx.y.  Sources of level 0 are the n0 points, of levels >= 1 the
-// level-0 blocks.  A source is the FIRST of its block when first[slot] == source index; the block's
-// occupancy mask is already final, so block ranks and voxel row bases are scanned together.
-// pass A: per SCAN_BLOCK sources: number of first occurrences, number of voxels they bring.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_first_count(PyramidArgs a, int lv0, int n0) {
-  __shared__ int lds[SCAN_BLOCK / 64];
-  const int l = lv0 + blockIdx.y;
-  if (a.counts[ABORT]) return;
-  const int n = l == 0 ? (a.n_dev ? min(n0, *a.n_dev) : n0) : a.counts[8];
-  if ((int)blockIdx.x * SCAN_BLOCK >= n) return;
-  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  int flag = 0, cnt = 0;
-  if (p < n) {
-    const int s = a.sslot[l][p];
-    if (s >= 0 && a.h[l].first[s] == p) {
-      flag = 1;
-      cnt = __popcll(a.h[l].mask[s]);
+// ranks the blocks of level l among n sources: returns (flag, slot, mask, block rank, voxel base) of this thread's source and
+// the workgroup's (first rank, number of first occurrences); false when the workgroup has no sources
+#if defined(SPS_FE_TRACE)  // DIAGNOSTIC build only (tools/fe_trace.py): wall-clock stamps (100 MHz) of the ranking workgroups
+__device__ unsigned long long g_fe_trace[8 * 4096];
+#define FE_STAMP(k) do { if (threadIdx.x == 0) g_fe_trace[8 * ((l == 0 ? 0 : 1024) + (FE_WG)) + (k)] = wall_clock64(); } while (0)
+#else
+#define FE_STAMP(k) do { } while (0)
+#endif
+#define FE_WG blockIdx.x
+struct Ranked {
+  int flag, slot, rank, base;
+  unsigned long long mask;
+  uint64_t key;
+  int wg_rank0, wg_blocks;
+};
+// Every thread takes ITEMS consecutive sources (ranks follow the source order).
+template <int ITEMS>
+__device__ inline bool rank_pass(const PyramidArgs &a, int l, int n, Ranked &o, int *lds, int2 *wave_off, int *sh_id) {
+  FE_STAMP(0);
+  if (threadIdx.x == 0) *sh_id = atomicAdd(&a.counts[TICKET + l], 1);
+  __syncthreads();
+  const int id = *sh_id;
+  FE_STAMP(1);
+  constexpr int PER_WG = SCAN_BLOCK * ITEMS;
+  const int nwg = (n + PER_WG - 1) / PER_WG;
+  if (id >= nwg) return false;  // (every larger id leaves too: nobody waits for this workgroup)
+  const int p0 = id * PER_WG + (int)threadIdx.x * ITEMS;
+  int s[ITEMS], cnt[ITEMS];
+  unsigned long long m[ITEMS];
+  int flags = 0, nf = 0, nv = 0;
+  if (ITEMS == 4 && p0 + 3 < n) {  // (the arrays hold whole multiples of 1024 sources and come from hipMalloc: 16-byte aligned)
+    const int4 v = *reinterpret_cast<const int4 *>(a.sslot[l] + p0);
+    s[0] = v.x, s[1 % ITEMS] = v.y, s[2 % ITEMS] = v.z, s[3 % ITEMS] = v.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) s[i] = p0 + i < n ? a.sslot[l][p0 + i] : -1;
+  }
+  // first / mask / key of every source's slot are fetched together (each dependent access of this chain costs a memory
+  // round trip of 1-2 us: the slots were written by the previous launch's atomics)
+  int first[ITEMS];
+  uint64_t key[ITEMS];
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    const int si = max(s[i], 0);
+    first[i] = a.h[l].first[si];
+    m[i] = a.h[l].mask[si];
+    key[i] = a.h[l].keys[si];
+  }
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    cnt[i] = 0;
+    if (s[i] >= 0 && first[i] == p0 + i) {
+      flags |= 1 << i;
+      cnt[i] = __popcll(m[i]);
+      ++nf, nv += cnt[i];
     }
   }
-  const int t0 = block_reduce_sum(flag, lds);
-  const int t1 = block_reduce_sum(cnt, lds);
-  if (threadIdx.x == 0) {
-    a.block_sums[l * a.sums_stride + 2 * blockIdx.x] = t0;
-    a.block_sums[l * a.sums_stride + 2 * blockIdx.x + 1] = t1;
-  }
-}
-
-// pass B: block rank and voxel base of every first occurrence; compact per-block arrays; counts.
-__global__ __launch_bounds__(SCAN_BLOCK) void k_first_rank(PyramidArgs a, int lv0, int n0) {
-  __shared__ int lds[SCAN_BLOCK / 64];
-  __shared__ int2 wave_off[SCAN_BLOCK / 64];
-  const int l = lv0 + blockIdx.y;
-  if (lv0 > 0 && a.counts[ABORT]) return;  // (level 0 ranks before anything can have overflowed)
-  const int n = l == 0 ? (a.n_dev ? min(n0, *a.n_dev) : n0) : a.counts[8];
-  const int nwg = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
-  if ((int)blockIdx.x >= nwg) return;  // counts were zeroed by the reset
-  const int p = blockIdx.x * SCAN_BLOCK + threadIdx.x;
-  int s = -1, flag = 0, cnt = 0;
-  unsigned long long m = 0;
-  if (p < n) {
-    s = a.sslot[l][p];
-    if (s >= 0 && a.h[l].first[s] == p) {
-      flag = 1;
-      m = a.h[l].mask[s];
-      cnt = __popcll(m);
+  int2 tot;
+  const int2 loc = block_exclusive_scan2(nf, nv, wave_off, tot);
+  unsigned long long *agg = a.agg + (size_t)l * a.agg_stride;
+  if (threadIdx.x == 0) __hip_atomic_store(agg + id, agg_pack(a.gen, tot.x, tot.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  FE_STAMP(2);
+  const int2 base = scan_lookback(agg, id, a.gen, lds, a.err);
+  FE_STAMP(3);
+  int r = base.x + loc.x, vb = base.y + loc.y;
+  o.flag = 0;
+  o.wg_rank0 = base.x, o.wg_blocks = tot.x;
+#pragma unroll
+  for (int i = 0; i < ITEMS; ++i) {
+    if (((flags >> i) & 1) && r < a.bcapl[l]) {
+      a.h[l].rank[s[i]] = r;
+      a.bslot[l][r] = s[i];
+      a.bkey[l][r] = key[i];
+      a.bmask[l][r] = m[i];
+      a.bbase[l][r] = vb;
+      int4 *ch = reinterpret_cast<int4 *>(a.bchild[l] + (size_t)r * 8);
+      ch[0] = make_int4(-1, -1, -1, -1);
+      ch[1] = make_int4(-1, -1, -1, -1);
+      if (ITEMS == 1) o.flag = 1, o.slot = s[i], o.rank = r, o.base = vb, o.mask = m[i], o.key = key[i];
     }
+    if ((flags >> i) & 1) ++r, vb += cnt[i];
   }
-  const int2 off = block_exclusive_scan2(flag, cnt, a.block_sums + l * a.sums_stride, lds, wave_off);
-  if (flag && off.x < a.bcapl[l]) {
-    const int r = off.x;
-    a.h[l].rank[s] = r;
-    a.bslot[l][r] = s;
-    a.bkey[l][r] = a.h[l].keys[s];
-    a.bmask[l][r] = m;
-    a.bbase[l][r] = off.y;
-    int4 *ch = reinterpret_cast<int4 *>(a.bchild[l] + (size_t)r * 8);
-    ch[0] = make_int4(-1, -1, -1, -1);
-    ch[1] = make_int4(-1, -1, -1, -1);
-  }
-  if ((int)blockIdx.x == nwg - 1 && threadIdx.x == SCAN_BLOCK - 1) {
-    a.counts[8 + l] = off.x + flag;
-    a.counts[l] = off.y + cnt;
-    if (off.x + flag > a.bcapl[l] || off.y + cnt > a.capl[l]) {  // this level does not fit its arrays: abort the forward
+  if (id == nwg - 1 && threadIdx.x == 0) {
+    const int nb = base.x + tot.x, nvx = base.y + tot.y;
+    a.counts[8 + l] = min(nb, a.bcapl[l]);  // (later kernels index per-block arrays with it)
+    a.counts[l] = nvx;
+    if (nb > a.bcapl[l] || nvx > a.capl[l]) {  // this level does not fit its arrays: abort the forward
       atomicOr(&a.counts[ABORT], 1);
       atomicOr(a.err, 2);
     }
   }
+  return true;
 }
 
-// point -> voxel row (inverse map of TensorField.sparse / slice, models.py:25,28); also records the
-// (block, bit) of every level-0 row (all points of a voxel write the same values).
-// Launched together with blocks_to_ancestors (both only need the level-0 block ranks): workgroups
-// [0, gp) map points to rows, the next 4 * gb insert the ancestor blocks of levels 1..4.
-__global__ __launch_bounds__(256) void k_rows_ancestors(const int *__restrict__ sslot, const unsigned char *__restrict__ sbit,
-                                                         int n, BHash h, const int *__restrict__ bbase,
-                                                         int *__restrict__ inv, int *__restrict__ vblock,
-                                                         unsigned char *__restrict__ vbit, PyramidArgs a, int gp, int gb) {
-  if (a.counts[ABORT]) return;  // level 0 overflowed: ranks and row bases are incomplete
-  if ((int)blockIdx.x >= gp) {
-    const int b = (int)blockIdx.x - gp;
-    blocks_to_ancestors(a, 1 + b / gb, b % gb, gb);
+// level 0: block ranks + voxel bases of the points' blocks, and -- from registers, no second pass over the blocks -- the
+// ancestor block of every new level-0 block at levels 1..4 (App. A.9: floor(c / 2ts) * 2ts applied l times = a right shift
+// of the biased coordinate).  A level-0 block covers 2x2x2 level-1 voxels (an octant of its parent block) and exactly one
+// voxel of levels 2..4.  Wave w of the workgroup inserts at level 1 + (w & 3) the blocks [64 (w >> 2) ...) step 256.
+__global__ __launch_bounds__(SCAN_BLOCK) void k_rank_points(PyramidArgs a, int n0) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int2 wave_off[SCAN_BLOCK / 64];
+  __shared__ int sh_id;
+  __shared__ uint64_t sh_key[SCAN_BLOCK];
+  __shared__ unsigned long long sh_mask[SCAN_BLOCK];
+  const int n = a.n_dev ? min(n0, *a.n_dev) : n0;
+  Ranked k;
+  if (!rank_pass<1>(a, 0, n, k, lds, wave_off, &sh_id)) return;
+  const int l = 0;
+  FE_STAMP(4);
+  uint32_t tb = 0u;
+  if (k.flag) {
+    const uint64_t key = k.key;
+    sh_key[k.rank - k.wg_rank0] = key;
+    sh_mask[k.rank - k.wg_rank0] = k.mask;
+    tb = 1u << (uint32_t)((key >> 54) & 0x1F);
+  }
+  for (int o = 32; o > 0; o >>= 1) tb |= __shfl_xor(tb, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = (int)tb;
+  __syncthreads();
+  if (threadIdx.x == 0) {  // one atomic per workgroup, and only for bits nobody has set yet (2 400 waves on one address cost 20 us)
+    for (int i = 1; i < SCAN_BLOCK / 64; ++i) tb |= (uint32_t)lds[i];
+    uint32_t *tocc = reinterpret_cast<uint32_t *>(a.counts) + TOCC;
+    if ((__hip_atomic_load(tocc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & tb) != tb) atomicOr(tocc, tb);
+  }
+  const int nb = min(k.wg_blocks, a.bcapl[0] - k.wg_rank0);  // (blocks beyond the capacity have no arrays: the forward aborts)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  FE_STAMP(5);
+  {
+  const int l = 1 + (wave & 3);
+  for (int j0 = (wave >> 2) * 64; j0 < nb; j0 += 256) {
+    const int j = j0 + lane;
+    const bool ok = j < nb;
+    uint64_t pkey = KEY_EMPTY;
+    unsigned long long pm = 0;
+    if (ok) {
+      const uint64_t key = sh_key[j];
+      const uint32_t bx = (uint32_t)(key & 0x3FFFF), by = (uint32_t)((key >> 18) & 0x3FFFF), bz = (uint32_t)((key >> 36) & 0x3FFFF);
+      const uint64_t bt = key & (0x3FFull << 54);
+      pkey = bt | ((uint64_t)(bz >> l) << 36) | ((uint64_t)(by >> l) << 18) | (uint64_t)(bx >> l);
+      if (l == 1) {
+        const unsigned long long m = sh_mask[j];
+        const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+          for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              if (m & (0x0000000000330033ull << (2 * i + 8 * jj + 32 * kk)))
+                pm |= 1ull << ((2 * oz + kk) * 16 + (2 * oy + jj) * 4 + (2 * ox + i));
+      } else {
+        const uint32_t px = (bx >> (l - 2)) & 3, py = (by >> (l - 2)) & 3, pz = (bz >> (l - 2)) & 3;
+        pm = 1ull << ((pz << 4) | (py << 2) | px);
+      }
+    }
+    const int r = k.wg_rank0 + j;
+    const int sl = wave_run_insert(a.h[l], pkey, ok, (uint32_t)pm, (uint32_t)(pm >> 32), r);
+    if (ok) a.sslot[l][r] = sl;
+  }
+  }
+  __syncthreads();
+  FE_STAMP(6);
+}
+
+// levels 1..4 (sources = the level-0 blocks) ranked in one launch: workgroups [0, 4 gsb) rank (level 1 + b / gsb; the ids
+// inside a level come from its ticket), the rest map points to voxel rows (inverse map of TensorField.sparse / slice,
+// models.py:25,28) and record the (block, bit) of every level-0 row (all points of a voxel write the same values) -- work
+// that only needs the level-0 ranks and rides along instead of holding up the ancestors.
+constexpr int RANK_ITEMS = 1;  // level-0 blocks per thread in the ranking of levels 1..4 (4: the gathers of a level land on 8 CUs, 19 us instead of 14)
+__global__ __launch_bounds__(SCAN_BLOCK) void k_rank_blocks_rows(PyramidArgs a, int gsb, int n0, int *__restrict__ inv) {
+  __shared__ int lds[SCAN_BLOCK / 64];
+  __shared__ int2 wave_off[SCAN_BLOCK / 64];
+  __shared__ int sh_id;
+  if ((int)blockIdx.x < 4 * gsb) {
+    // (no early exit on ABORT here: a workgroup that left without publishing would be waited for; counts[8] is clamped)
+    // the grid is sized for "every point its own block": exactly the workgroups whose own chunk exists take a ticket (as many
+    // as there are chunks), the others leave at once instead of queueing on the ticket (600 atomics on one line: 9 us)
+    const int nblk = a.counts[8];
+    if (((int)blockIdx.x % gsb) * (SCAN_BLOCK * RANK_ITEMS) >= nblk) return;
+    Ranked k;
+    rank_pass<RANK_ITEMS>(a, 1 + (int)blockIdx.x / gsb, nblk, k, lds, wave_off, &sh_id);
+    const int l = 1;
+    FE_STAMP(4);
     return;
   }
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (a.n_dev) n = min(n, *a.n_dev);
+  if (a.counts[ABORT]) return;  // level 0 overflowed: ranks and row bases are incomplete
+  const int l = 1;
+  FE_STAMP(0);
+  const int n = a.n_dev ? min(n0, *a.n_dev) : n0;
+  const int p = ((int)blockIdx.x - 4 * gsb) * SCAN_BLOCK + (int)threadIdx.x;
   if (p >= n) return;
-  const int s = sslot[p];
+  const int s = a.sslot[0][p];
   int row = -1;
   if (s >= 0) {
+    const BHash &h = a.h[0];
     const int r = h.rank[s];
-    const int bit = sbit[p];
-    row = bbase[r] + __popcll(h.mask[s] & ((1ull << bit) - 1ull));
-    vblock[row] = r;
-    vbit[row] = (unsigned char)bit;
+    const int bit = a.sbit0[p];
+    row = a.bbase[0][r] + __popcll(h.mask[s] & ((1ull << bit) - 1ull));
+    a.vblock[0][row] = r;
+    a.vbit[0][row] = (unsigned char)bit;
   }
   inv[p] = row;
+  FE_STAMP(6);
 }
 
 // blockIdx.y = l in 0..3.  (a) parent / child block links between level l and l+1 (one hash probe per
@@ -393,6 +495,7 @@ __device__ inline void link_levels(const PyramidArgs &a, int l, int bx, int nbx)
 // in {-1,0,1}^4, a = (dbx+1) + 3(dby+1) + 9(dbz+1) + 27(dt+1), or -1.  The only hash probes of the
 // kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
 // One launch with link_levels (both only need the block ranks of all levels): workgroups [0, 4 * gb) link.
+// A scan + submap batch holds two time indices (util.py:20-21): a third of the probes is answered by the TOCC bits.
 __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1, int c2, int c3, int c4, int c5) {
   if (a.counts[ABORT]) return;
   if ((int)blockIdx.x < 4 * gb) {
@@ -407,6 +510,7 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
   const int total = a.counts[8 + level] * 81;  // < 2^31: blocks <= points <= 2^23
   const int lim = 1 << (16 - level);  // block coordinates of this level live in [0, lim)
   const BHash h = a.h[level];
+  const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];  // a time index no block has needs no probe
   for (int i = (bx - lo) * blockDim.x + threadIdx.x; i < total; i += (hi - lo) * blockDim.x) {
     const int r = i / 81, ad = i - r * 81;
     const uint64_t key = a.bkey[level][r];
@@ -415,7 +519,7 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
     int res = -1;
     if (ad == 40) {
       res = r;
-    } else if (bxx >= 0 && bxx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32) {
+    } else if (bxx >= 0 && bxx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32 && ((tocc >> tt) & 1u)) {
       const int s = bhash_find(h, bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bxx, (uint32_t)by, (uint32_t)bz));
       if (s >= 0) res = h.rank[s];
     }

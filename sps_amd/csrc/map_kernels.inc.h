@@ -116,11 +116,21 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   unsigned char *__restrict__ rbk = a.rb_k[l];
   int *__restrict__ rbc = a.rb_cnt[l];
   const unsigned long long ltm = (1ull << lane) - 1ull;
+  const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];
   for (int u = local * 256 + (int)threadIdx.x; u < nround; u += nchunks * 256) {
     const bool ok = u < n;
     const int r = ok ? L.vblock[u] : 0;
     const int bit = ok ? L.vbit[u] : 0;
     const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
+    // time slice dt = slice - 1 of a row at time index t is empty when no block of the forward has index t + dt (a scan +
+    // submap batch holds two indices: a third of the (row, slice) walks ends here)
+    const int nt = ok ? (int)((L.bkey[r] >> 54) & 0x1F) + slice - 1 : -1;
+    const bool act = nt >= 0 && nt < 32 && ((tocc >> nt) & 1u);
+    if (!__any(act)) {
+      if ((lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = 0u;
+      if (rbc && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = 0;
+      continue;
+    }
     const int *__restrict__ adj = L.badj + (size_t)r * 81 + slice * 27;
     // the run x = px-1 .. px+1 touches the block at offset 0 and at most one of the blocks at -1 / +1
     const int side = px == 0 ? -1 : (px == 3 ? 1 : 0);
@@ -134,8 +144,8 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       const int ty = py + dy, tz = pz + dz;
       const int ad0 = ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
       const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
-      const int nb_c = ok ? adj[ad0] : -1;
-      const int nb_s = (ok && side != 0) ? adj[ad0 + side] : -1;
+      const int nb_c = act ? adj[ad0] : -1;
+      const int nb_s = (act && side != 0) ? adj[ad0 + side] : -1;
       const unsigned long long mk_c = nb_c >= 0 ? L.bmask[nb_c] : 0ull;
       const int base_c = nb_c >= 0 ? L.bbase[nb_c] : 0;
       const unsigned long long mk_s = nb_s >= 0 ? L.bmask[nb_s] : 0ull;

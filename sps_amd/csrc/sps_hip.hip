@@ -245,6 +245,7 @@ struct sps_ctx {
   int *counts = nullptr;     // device: [0..4] voxels per level, [5] submap rows, [6] scan voxels, [8..12] blocks per level
   int *err = nullptr;        // device error flag
   int *block_sums = nullptr;
+  unsigned long long *scan_agg = nullptr;  // single-pass ranking: one generation-tagged word per logical workgroup and level
   int *keep = nullptr;
   double *macc = nullptr;    // metrics accumulators [32*8]
   unsigned long long *pairs = nullptr;  // [128]
@@ -253,7 +254,7 @@ struct sps_ctx {
   float *ss = nullptr;       // folded scale/shift
   float *wu = nullptr;       // unit-major permuted conv kernels (k_conv B operand)
   uint32_t *tm5 = nullptr;
-  void *zero_region = nullptr;  // [counts (16 ints) | all tile masks]: one fill per forward
+  void *zero_region = nullptr;  // [counters (N_COUNTERS ints) | all tile masks]: the counters are cleared by every forward
   size_t zero_bytes = 0;
   float final_bias = 0.f;
   const NetSpec *net = nullptr;  // layout of the loaded weights: spec(out_channels)
@@ -420,7 +421,7 @@ int reserve(sps_ctx *c, int64_t n) {
     ALLOC(c->sub.srckey, uint64_t, cap);
     ALLOC(c->sub.pslot, int, cap);
   }
-  size_t zr_words = 16;
+  size_t zr_words = N_COUNTERS;
   {
     auto tmw = [&](int l) { return (size_t)(c->capl[l] / 16) * 4; };  // capacities are multiples of 1024
     zr_words += tmw(0);
@@ -431,9 +432,9 @@ int reserve(sps_ctx *c, int64_t n) {
     c->zero_region = zr;
     // zeroed at the start of every forward: the counters only.  Every tile-mask array behind them is overwritten
     // tile by tile by the forward that uses it (the 5x5x5 debug masks are cleared by their getter)
-    c->zero_bytes = 16 * sizeof(uint32_t);
+    c->zero_bytes = N_COUNTERS * sizeof(uint32_t);
     c->counts = reinterpret_cast<int *>(zr);
-    uint32_t *p = zr + 16;
+    uint32_t *p = zr + N_COUNTERS;
     c->tm5 = p;
     p += tmw(0);
     for (int l = 1; l < SPS_NUM_LEVELS; ++l) {
@@ -446,6 +447,9 @@ int reserve(sps_ctx *c, int64_t n) {
     }
   }
   ALLOC(c->block_sums, int, 2 * (cap / SCAN_BLOCK + 8) * SPS_NUM_LEVELS);
+  const size_t agg_words = (size_t)(cap / SCAN_BLOCK + 8) * NLV;
+  ALLOC(c->scan_agg, unsigned long long, agg_words);
+  HIP_TRY(hipMemset(c->scan_agg, 0, sizeof(unsigned long long) * agg_words));
   ALLOC(c->keep, int, cap);
   const int64_t *cl = c->capl;
   ALLOC(c->cat8, float, 16 * cap);
@@ -527,8 +531,10 @@ PyramidArgs pyramid_args(sps_ctx *c) {
     a.vbit[l] = L.vbit;
   }
   a.counts = c->counts;
-  a.block_sums = c->block_sums;
-  a.sums_stride = (int)(2 * (c->cap / SCAN_BLOCK + 8));
+  a.sbit0 = c->lv[0].sbit;
+  a.agg = c->scan_agg;
+  a.agg_stride = (int)(c->cap / SCAN_BLOCK + 8);
+  a.gen = (uint32_t)(c->fwd_gen % 0xFFFFFFFFull) + 1u;  // never 0 (the value the array starts with)
   a.n_dev = nullptr;
   for (int l = 0; l < NLV; ++l) {
     a.capl[l] = (int)c->capl[l];
@@ -1242,24 +1248,16 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   // ---- level 0: points -> blocks -> voxel rows
   const unsigned gp = (unsigned)((n + 255) / 256);
   const unsigned gs0 = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-  const unsigned gsb = (unsigned)(cap / SCAN_BLOCK);  // bound for scans over blocks
+  const unsigned gsb = (unsigned)((cap + SCAN_BLOCK * RANK_ITEMS - 1) / (SCAN_BLOCK * RANK_ITEMS));  // bound for scans over blocks
   // (the first kernel also clears the counters and tile masks of the previous forward)
   hipLaunchKernelGGL(k_points_to_blocks, dim3(gp), dim3(256), 0, st, coords, ld, (int)n, vs, fo.t_base, L0.h, L0.sslot, L0.sbit,
                      c->err, reinterpret_cast<uint4 *>(c->zero_region), (int)(c->zero_bytes / 16), fo.metrics_out,
                      fo.metrics_out ? fo.n_batches * 8 : 0, fo.n_dev);
-  hipLaunchKernelGGL(k_first_count, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
-  hipLaunchKernelGGL(k_first_rank, dim3(gs0, 1), dim3(SCAN_BLOCK), 0, st, pa, 0, (int)n);
-  // ---- point rows + (levels 1..4) every coarser level straight from the level-0 blocks, one launch
+  // block ranks + voxel bases of level 0 in one pass; the same launch inserts every new block's ancestors at levels 1..4
+  hipLaunchKernelGGL(k_rank_points, dim3(gs0), dim3(SCAN_BLOCK), 0, st, pa, (int)n);
+  // ---- levels 1..4 ranked from the level-0 blocks (one pass, batched over levels) + point -> voxel row, one launch
+  hipLaunchKernelGGL(k_rank_blocks_rows, dim3(4 * gsb + gs0), dim3(SCAN_BLOCK), 0, st, pa, (int)gsb, (int)n, L0.inv);
   const int gb = grid_for(cap >> 2, 256, 256);
-  if (no_merge & 1) {
-    hipLaunchKernelGGL(k_rows_ancestors, dim3(gp), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
-                       L0.vblock, L0.vbit, pa, (int)gp, gb);
-    hipLaunchKernelGGL(k_rows_ancestors, dim3(4 * gb), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase, L0.inv,
-                       L0.vblock, L0.vbit, pa, 0, gb);
-  } else {
-    hipLaunchKernelGGL(k_rows_ancestors, dim3(gp + 4 * gb), dim3(256), 0, st, L0.sslot, L0.sbit, (int)n, L0.h, L0.bbase,
-                       L0.inv, L0.vblock, L0.vbit, pa, (int)gp, gb);
-  }
   if (fo.feats) {  // voxel feature = mean of its points' features (App. A.4)
     HIP_TRY(hipMemsetAsync(c->vacc, 0, (size_t)n * sizeof(long long), st));  // V <= n rows are used
     HIP_TRY(hipMemsetAsync(c->vcnt, 0, (size_t)n * sizeof(int), st));
@@ -1268,9 +1266,6 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
                        c->vcnt, c->vfeat);
   }
   prof_mark(c, "voxelize", st);
-  // ---- levels 1..4: every coarser level straight from the level-0 blocks, batched over levels
-  hipLaunchKernelGGL(k_first_count, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
-  hipLaunchKernelGGL(k_first_rank, dim3(gsb, 4), dim3(SCAN_BLOCK), 0, st, pa, 1, 0);
   // ---- level links + block adjacency, one launch
   // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
   {
@@ -1429,6 +1424,7 @@ static int report_device_errors(sps_ctx *c, int e, hipStream_t st) {
                                "sps_ctx_set_level_fractions): the forward was aborted and its scores are NaN; the context "
                                "has switched to full-size arenas, re-issue the forward");
   }
+  if (e & 16) return fail(SPS_ERR_HIP, "internal: a ranking workgroup waited for a predecessor that never published (results of that forward are invalid)");
   if (e & 8)
     return fail(SPS_ERR_INVALID, "train-mode BatchNorm: a level of the training forward had a single active row (Expected more "
                                  "than 1 value per channel when training)");
@@ -1911,6 +1907,13 @@ int sps_get_logits(sps_ctx *c, float *logits_dev) {
   return SPS_OK;
 }
 
+#if defined(SPS_FE_TRACE)
+int sps_debug_fe_trace(unsigned long long *host, int n) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fe_trace), (size_t)n * 8 * sizeof(unsigned long long)));
+  return SPS_OK;
+}
+#endif
 #if defined(SPS_WAVE_TRACE)
 // diagnostic builds only; not part of include/sps_hip.h
 int sps_debug_wave_trace(unsigned long long *host, int n_waves) {
