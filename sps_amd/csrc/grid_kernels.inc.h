@@ -146,6 +146,7 @@ struct PyramidArgs {
   uint64_t *bkey[NLV];
   unsigned long long *bmask[NLV];
   int *bbase[NLV];
+  uint4 *bmb[NLV];
   int *bparent[NLV];
   int *bchild[NLV];
   int *badj[NLV];
@@ -312,6 +313,7 @@ __device__ inline bool rank_pass(const PyramidArgs &a, int l, int n, Ranked &o, 
       a.bkey[l][r] = key[i];
       a.bmask[l][r] = m[i];
       a.bbase[l][r] = vb;
+      a.bmb[l][r] = make_uint4((uint32_t)m[i], (uint32_t)(m[i] >> 32), (uint32_t)vb, 0u);
       int4 *ch = reinterpret_cast<int4 *>(a.bchild[l] + (size_t)r * 8);
       ch[0] = make_int4(-1, -1, -1, -1);
       ch[1] = make_int4(-1, -1, -1, -1);

@@ -15,6 +15,7 @@ struct LevelView {
   const int *badj;
   const int *bparent;
   const int *bchild;
+  const uint4 *bmb;  // (mask lo, mask hi, row base, -) of every block: one 16-byte load where the kernel maps need both
 };
 
 // bit k of tile (u >> 4): "some row of the 16-row tile has a neighbour through offset k".
@@ -132,48 +133,79 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       continue;
     }
     const int *__restrict__ adj = L.badj + (size_t)r * 81 + slice * 27;
-    // the run x = px-1 .. px+1 touches the block at offset 0 and at most one of the blocks at -1 / +1
-    const int side = px == 0 ? -1 : (px == 3 ? 1 : 0);
+    // The 3x3x3 neighbourhood of a voxel touches at most two blocks per axis (its own and, from a face voxel, the one
+    // behind that face): the up to 8 blocks (mask, row base) are fetched ONCE -- 3.4 on average, against 18 adjacency + 36
+    // mask / base loads when every (dy, dz) run fetched its own -- and every offset selects among them in registers.
+    const int sx = px == 0 ? -1 : (px == 3 ? 1 : 0), sy = py == 0 ? -1 : (py == 3 ? 1 : 0), sz = pz == 0 ? -1 : (pz == 3 ? 1 : 0);
+    uint32_t mlo[8], mhi[8];
+    int bs[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const bool need = act && (!(c & 1) || sx != 0) && (!(c & 2) || sy != 0) && (!(c & 4) || sz != 0);
+      const int e = (((c & 4) ? sz : 0) + 1) * 9 + (((c & 2) ? sy : 0) + 1) * 3 + (((c & 1) ? sx : 0) + 1);
+      int nb = -1;
+      if (need) nb = (c == 0 && slice == 1) ? r : adj[e];  // (entry 40 of the table is the block itself)
+      uint4 q = make_uint4(0u, 0u, 0u, 0u);
+      if (nb >= 0) q = L.bmb[nb];
+      mlo[c] = q.x, mhi[c] = q.y, bs[c] = (int)q.z;
+    }
     uint32_t m = 0u;
     int cb = 0;  // chunks written to the segment so far
+    int klo = 0, khi = 0;
     uint32_t *__restrict__ eb = rbe ? rbe + ((size_t)(u >> 6) * PX_CH_MAX + (size_t)slice * PX_SEG_CH) * 16 : nullptr;
     unsigned char *__restrict__ kb = rbk ? rbk + (size_t)(u >> 6) * PX_KSTRIDE + slice * 112 : nullptr;
-#pragma unroll 3
-    for (int c = 0; c < 9; ++c) {
-      const int dy = c % 3 - 1, dz = c / 3 - 1;
-      const int ty = py + dy, tz = pz + dz;
-      const int ad0 = ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1;
-      const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
-      const int nb_c = act ? adj[ad0] : -1;
-      const int nb_s = (act && side != 0) ? adj[ad0 + side] : -1;
-      const unsigned long long mk_c = nb_c >= 0 ? L.bmask[nb_c] : 0ull;
-      const int base_c = nb_c >= 0 ? L.bbase[nb_c] : 0;
-      const unsigned long long mk_s = nb_s >= 0 ? L.bmask[nb_s] : 0ull;
-      const int base_s = nb_s >= 0 ? L.bbase[nb_s] : 0;
+    // (all 27 offsets unrolled: 125 VGPRs + spilled SGPRs, 29 us instead of 22.  Measured and dropped as well: 32-bit halves of
+    //  the masks + the per-tile bits kept in scalar registers -- fewer VALU instructions, 98 VGPRs, 27 us)
+#pragma unroll 1
+    for (int dz = -1; dz <= 1; ++dz) {
+      const int tz = pz + dz;
+      const bool oz = (tz >> 2) != 0;
+      uint32_t zlo[4], zhi[4];
+      int zb[4];
 #pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int tx = px + dx;
-        const bool centre = (tx >> 2) == 0;
-        const unsigned long long mk = centre ? mk_c : mk_s;
-        const int base = centre ? base_c : base_s;
-        const int nbit = nbit0 | (tx & 3);
-        int row = -1;
-        if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
-        const int j = 3 * c + dx + 1;  // bit inside the slice word
-        const unsigned long long bal = __ballot(row >= 0);
-        const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
-        // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
-        if (any && ok && nbr) nbr[(size_t)(27 * slice + j) * ldn + u] = row;  // (inference-only contexts keep no table here)
-        m |= any ? 1u << j : 0u;
-        if (eb) {  // wave-uniform
-          const int cnt = __popcll(bal);
-          if (row >= 0) eb[cb * 16 + __popcll(bal & ltm)] = ((uint32_t)row << 6) | (uint32_t)lane;
-          if (lane < ((-cnt) & 15)) eb[cb * 16 + cnt + lane] = PX_PAD;
-          const int nc = (cnt + 15) >> 4;
-          if (lane < nc) kb[cb + lane] = (unsigned char)(27 * slice + j);
-          cb += nc;
+      for (int k = 0; k < 4; ++k) zlo[k] = oz ? mlo[k + 4] : mlo[k], zhi[k] = oz ? mhi[k + 4] : mhi[k], zb[k] = oz ? bs[k + 4] : bs[k];
+#pragma unroll
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int ty = py + dy;
+        const bool oy = (ty >> 2) != 0;
+        const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
+        uint32_t ylo[2], yhi[2];
+        int yb[2];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) ylo[k] = oy ? zlo[k + 2] : zlo[k], yhi[k] = oy ? zhi[k + 2] : zhi[k], yb[k] = oy ? zb[k + 2] : zb[k];
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int tx = px + dx;
+          const bool ox = (tx >> 2) != 0;
+          const unsigned long long mk = ((unsigned long long)(ox ? yhi[1] : yhi[0]) << 32) | (ox ? ylo[1] : ylo[0]);
+          const int base = ox ? yb[1] : yb[0];
+          const int nbit = nbit0 | (tx & 3);
+          int row = -1;
+          if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
+          const int j = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);  // bit inside the slice word
+          const unsigned long long bal = __ballot(row >= 0);
+          const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
+          // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
+          if (any && ok && nbr) nbr[(size_t)(27 * slice + j) * ldn + u] = row;  // (inference-only contexts keep no table here)
+          m |= any ? 1u << j : 0u;
+          if (eb) {  // wave-uniform
+            // ONE store per offset: lanes with a pair write their entry at its compacted slot, the first (-cnt & 15) lanes
+            // without one write the padding behind the entries (there are always enough: cnt > 48 => 64 - cnt = the padding)
+            const int cnt = __popcll(bal);
+            const int pos = row >= 0 ? __popcll(bal & ltm) : cnt + __popcll(~bal & ltm);
+            if (row >= 0 || pos < ((cnt + 15) & ~15)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 6) | (uint32_t)lane : PX_PAD;
+            cb += (cnt + 15) >> 4;
+            // chunk -> offset table: chunk q belongs to offset #{j' : chunks up to and including j' <= q}, counted per lane for
+            // q = lane and q = lane + 64 and stored once at the end
+            klo += lane >= cb ? 1 : 0;
+            khi += lane + 64 >= cb ? 1 : 0;
+          }
         }
       }
+    }
+    if (eb) {
+      if (lane < cb) kb[lane] = (unsigned char)(27 * slice + klo);
+      if (lane + 64 < cb) kb[lane + 64] = (unsigned char)(27 * slice + khi);
     }
     if ((lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = m;
     if (eb && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = cb;
@@ -255,13 +287,26 @@ __device__ inline void build_stride_maps(const MapsArgs &a, int bid) {
 // (256 rows of one time slice each: chunk = bid % nchunk, slice = bid / nchunk), the rest the stride maps (down / up) of the four level pairs.
 // (conv0, which also only needs the block structure, stays a launch of its own: merged in here it costs the map
 //  part two waves of occupancy and overlaps with nothing: 63 us merged vs 59 us apart)
+#if defined(SPS_FE_TRACE)  // DIAGNOSTIC build only (tools/fe_trace.py)
+__device__ unsigned long long g_maps_trace[2 * 16384];
+#endif
 __global__ __launch_bounds__(256) void k_maps(MapsArgs ma, int nchunk, int n_nbr) {
   if (ma.counts[ABORT]) return;
   const int bid = (int)blockIdx.x;
+#if defined(SPS_FE_TRACE)
+  if (threadIdx.x == 0 && bid < 16384) g_maps_trace[2 * bid] = wall_clock64();
+#endif
   if (bid < n_nbr)
+    // (bound by instruction issue: ~2 us per active wave and slice, 12 us per workgroup with 6 waves per SIMD.  Launching the
+    //  slice every row walks, dt = 0, FIRST was measured: 25.3 us instead of 22.2 -- the light workgroups of the half-empty
+    //  slices mix better with the heavy ones than they fill in behind them)
     build_nbr3(ma, bid % nchunk, bid / nchunk);
   else
     build_stride_maps(ma, bid - n_nbr);
+#if defined(SPS_FE_TRACE)
+  __syncthreads();
+  if (threadIdx.x == 0 && bid < 16384) g_maps_trace[2 * bid + 1] = wall_clock64();
+#endif
 }
 
 // pairs per offset from the rulebook (inference-only contexts keep no neighbour table at the pair-exact levels):

@@ -151,6 +151,7 @@ struct Level {
   uint64_t *bkey = nullptr;
   unsigned long long *bmask = nullptr;
   int *bbase = nullptr;
+  uint4 *bmb = nullptr;
   int *bparent = nullptr;  // rank of the parent block (level + 1)
   int *bchild = nullptr;   // [cap][8] rank of the child block (level - 1) per octant
   int *badj = nullptr;     // [cap][81]
@@ -172,7 +173,7 @@ struct Level {
   uint32_t *rb_e = nullptr;       // [cap/64][PX_CH_MAX][16] pair entries
   unsigned char *rb_k = nullptr;  // [cap/64][PX_KSTRIDE] offset of each chunk
   int *rb_cnt = nullptr;          // [cap/64][4] chunks per time slice
-  LevelView view() const { return LevelView{vblock, vbit, bkey, bmask, bbase, badj, bparent, bchild}; }
+  LevelView view() const { return LevelView{vblock, vbit, bkey, bmask, bbase, badj, bparent, bchild, bmb}; }
 };
 
 struct SubmapScratch {  // variant-B submap: voxel-level hash with first-occurrence order
@@ -377,6 +378,7 @@ int reserve(sps_ctx *c, int64_t n) {
       ALLOC(L.bkey, uint64_t, blocks);
       ALLOC(L.bmask, unsigned long long, blocks);
       ALLOC(L.bbase, int, blocks);
+      ALLOC(L.bmb, uint4, blocks);
       ALLOC(L.bparent, int, blocks);
       ALLOC(L.bchild, int, 8 * blocks);
       ALLOC(L.badj, int, 81 * blocks);
@@ -524,6 +526,7 @@ PyramidArgs pyramid_args(sps_ctx *c) {
     a.bkey[l] = L.bkey;
     a.bmask[l] = L.bmask;
     a.bbase[l] = L.bbase;
+    a.bmb[l] = L.bmb;
     a.bparent[l] = L.bparent;
     a.bchild[l] = L.bchild;
     a.badj[l] = L.badj;
@@ -1198,6 +1201,9 @@ int sps_forward_metrics_n(sps_ctx *c, const float *batch, int64_t ld, int64_t n_
   return forward_impl(c, batch, ld, n_max, vs, scores, fo, stream);
 }
 
+#if defined(SPS_FE_TRACE)
+static int g_maps_geom[8];
+#endif
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
                         const ForwardOpts &fo, void *stream) {
   if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
@@ -1300,6 +1306,10 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     if (((px_levels() >> l) & 1) && !fo.front_only) ma.rb_e[l] = c->lv[l].rb_e, ma.rb_k[l] = c->lv[l].rb_k, ma.rb_cnt[l] = c->lv[l].rb_cnt;
   for (int l = 0; l < NLV; ++l) ma.ldn[l] = c->capl[l];
   // (the 5x5x5x1 map is never materialised: conv0 is fused with it, k_conv0_fused)
+#if defined(SPS_FE_TRACE)
+  g_maps_geom[0] = off;
+  for (int l = 0; l <= NLV; ++l) g_maps_geom[1 + l] = ma.chunk_off[l];
+#endif
   if (no_merge & 4) {
     hipLaunchKernelGGL(k_maps, dim3(off * 3), dim3(256), 0, st, ma, off, off * 3);
     hipLaunchKernelGGL(k_maps, dim3(ma.chunk_off[NLV - 1]), dim3(256), 0, st, ma, off, 0);
@@ -1911,6 +1921,12 @@ int sps_get_logits(sps_ctx *c, float *logits_dev) {
 int sps_debug_fe_trace(unsigned long long *host, int n) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fe_trace), (size_t)n * 8 * sizeof(unsigned long long)));
+  return SPS_OK;
+}
+int sps_debug_maps_trace(unsigned long long *host, int n, int *geom /* [0] nchunk, [1..6] chunk_off */) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_maps_trace), (size_t)n * 2 * sizeof(unsigned long long)));
+  for (int i = 0; i < 8; ++i) geom[i] = g_maps_geom[i];
   return SPS_OK;
 }
 #endif

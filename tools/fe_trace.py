@@ -33,3 +33,25 @@ for lo, hi, title in ((0, 1024, "k_rank_points"), (1024, 4096, "k_rank_blocks_ro
         v = (tt[:, k] - t0) / 100.0
         v = v[tt[:, k] > 0]
         if len(v): print(f"  {nm:14s} n={len(v):4d} min {v.min():7.2f} median {np.median(v):7.2f} max {v.max():7.2f} us")
+
+n = 16384
+buf = (C.c_ulonglong * (2 * n))()
+geom = (C.c_int * 8)()
+fn = _native.lib.sps_debug_maps_trace
+fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+_native.check(fn(buf, n, geom))
+t = np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).astype(np.int64)
+nchunk, co = geom[0], list(geom)[1:7]
+valid = t[:, 0] > 0
+t0 = t[valid, 0].min()
+print("k_maps: nchunk", nchunk, "chunk_off", co, "traced workgroups", int(valid.sum()))
+def show(name, idx):
+    idx = [i for i in idx if i < n and t[i, 0] > 0 and t[i, 1] > 0]
+    if not idx: return
+    st = (t[idx, 0] - t0) / 100.0; en = (t[idx, 1] - t0) / 100.0
+    print(f"  {name:22s} n={len(idx):5d} start med {np.median(st):6.2f} max {st.max():6.2f} | end med {np.median(en):6.2f} max {en.max():6.2f} | dur med {np.median(en - st):6.2f} max {(en - st).max():6.2f} us")
+for pos, sl in enumerate((0, 1, 2)):     # launch order of the time slices
+    for l in range(5):
+        show(f"nbr3 level {l} slice {sl}", range(pos * nchunk + co[l], pos * nchunk + co[l + 1]))
+for f in range(4):
+    show(f"stride maps {f}->{f+1}", range(3 * nchunk + co[f], 3 * nchunk + co[f + 1]))
