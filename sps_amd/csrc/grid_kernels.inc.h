@@ -38,6 +38,13 @@ __device__ inline int bhash_insert(const BHash &h, uint64_t key) {
 }
 // Lookups run in later launches than the inserts.  Most probes of the adjacency build miss: the
 // occupancy bitmap (hcap/8 bytes, L2-resident) answers them without touching the 8-byte key array.
+__device__ inline int bhash_find_from(const BHash &h, uint64_t key, uint32_t s) {
+  while (true) {
+    if (!((h.occ[s >> 5] >> (s & 31)) & 1u)) return -1;
+    if (h.keys[s] == key) return (int)s;
+    s = (s + 1) & h.hmask;
+  }
+}
 __device__ inline int bhash_find(const BHash &h, uint64_t key) {
   uint32_t s = hash64(key) & h.hmask;
   while (true) {
@@ -498,34 +505,79 @@ __device__ inline void link_levels(const PyramidArgs &a, int l, int bx, int nbx)
 // kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
 // One launch with link_levels (both only need the block ranks of all levels): workgroups [0, 4 * gb) link.
 // A scan + submap batch holds two time indices (util.py:20-21): a third of the probes is answered by the TOCC bits.
+constexpr int LINK_ILP = 4;  // adjacency entries a thread resolves at once
+#if defined(SPS_FE_TRACE)
+__device__ unsigned long long g_link_trace[2 * 16384];
+struct LinkStamp {
+  __device__ LinkStamp() { if (threadIdx.x == 0 && blockIdx.x < 16384) g_link_trace[2 * blockIdx.x] = wall_clock64(); }
+  __device__ ~LinkStamp() { if (threadIdx.x == 0 && blockIdx.x < 16384) g_link_trace[2 * blockIdx.x + 1] = wall_clock64(); }
+};
+#endif
 __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1, int c2, int c3, int c4, int c5) {
   if (a.counts[ABORT]) return;
+#if defined(SPS_FE_TRACE)
+  LinkStamp stamp;
+#endif
   if ((int)blockIdx.x < 4 * gb) {
     link_levels(a, (int)blockIdx.x / gb, (int)blockIdx.x % gb, gb);
     return;
   }
-  // workgroup -> (level, chunk): chunk offsets 0, c1, c2, c3, c4, c5 (expected sizes, grid-stride beyond)
+  // workgroup -> (level, chunk): chunk offsets 0, c1, c2, c3, c4, c5 (expected sizes, grid-stride beyond), COARSEST level
+  // first: its few workgroups have the longest dependent chains and used to start last.
+  // The launch is bound by residency x latency, not by work: a workgroup holds its slot for the ~2.3 us of the dependent
+  // chain key -> occupancy word -> slot key -> rank whatever it does (8 700 one-probe workgroups: 12 us until the last one
+  // STARTED), so a thread walks LINK_ILP entries at once, phase by phase: the loads of a phase are independent.
   const int bx = (int)blockIdx.x - 4 * gb;
-  const int level = bx < c1 ? 0 : bx < c2 ? 1 : bx < c3 ? 2 : bx < c4 ? 3 : 4;
-  const int lo = level == 0 ? 0 : level == 1 ? c1 : level == 2 ? c2 : level == 3 ? c3 : c4;
-  const int hi = level == 0 ? c1 : level == 1 ? c2 : level == 2 ? c3 : level == 3 ? c4 : c5;
+  const int idx = bx < c1 ? 0 : bx < c2 ? 1 : bx < c3 ? 2 : bx < c4 ? 3 : 4;
+  const int level = NLV - 1 - idx;
+  const int lo = idx == 0 ? 0 : idx == 1 ? c1 : idx == 2 ? c2 : idx == 3 ? c3 : c4;
+  const int hi = idx == 0 ? c1 : idx == 1 ? c2 : idx == 2 ? c3 : idx == 3 ? c4 : c5;
   const int total = a.counts[8 + level] * 81;  // < 2^31: blocks <= points <= 2^23
   const int lim = 1 << (16 - level);  // block coordinates of this level live in [0, lim)
   const BHash h = a.h[level];
   const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];  // a time index no block has needs no probe
-  for (int i = (bx - lo) * blockDim.x + threadIdx.x; i < total; i += (hi - lo) * blockDim.x) {
-    const int r = i / 81, ad = i - r * 81;
-    const uint64_t key = a.bkey[level][r];
-    const int bxx = (int)(key & 0x3FFFF) + (ad % 3 - 1), by = (int)((key >> 18) & 0x3FFFF) + ((ad / 3) % 3 - 1),
-              bz = (int)((key >> 36) & 0x3FFFF) + ((ad / 9) % 3 - 1), tt = (int)((key >> 54) & 0x1F) + (ad / 27 - 1);
-    int res = -1;
-    if (ad == 40) {
-      res = r;
-    } else if (bxx >= 0 && bxx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32 && ((tocc >> tt) & 1u)) {
-      const int s = bhash_find(h, bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bxx, (uint32_t)by, (uint32_t)bz));
-      if (s >= 0) res = h.rank[s];
+  const uint64_t *__restrict__ bkey = a.bkey[level];
+  int *__restrict__ badj = a.badj[level];
+  for (int i0 = (bx - lo) * (256 * LINK_ILP) + (int)threadIdx.x; i0 < total; i0 += (hi - lo) * (256 * LINK_ILP)) {
+    uint64_t nk[LINK_ILP];
+    uint32_t sl[LINK_ILP];
+    int res[LINK_ILP];
+    bool probe[LINK_ILP];
+#pragma unroll
+    for (int u = 0; u < LINK_ILP; ++u) {
+      const int i = i0 + u * 256;
+      const int r = min(i, total - 1) / 81, ad = min(i, total - 1) - r * 81;
+      const uint64_t key = bkey[r];
+      const int bxx = (int)(key & 0x3FFFF) + (ad % 3 - 1), by = (int)((key >> 18) & 0x3FFFF) + ((ad / 3) % 3 - 1),
+                bz = (int)((key >> 36) & 0x3FFFF) + ((ad / 9) % 3 - 1), tt = (int)((key >> 54) & 0x1F) + (ad / 27 - 1);
+      res[u] = ad == 40 ? r : -1;
+      probe[u] = i < total && ad != 40 && bxx >= 0 && bxx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32 &&
+                 ((tocc >> tt) & 1u);
+      nk[u] = bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bxx, (uint32_t)by, (uint32_t)bz);
+      sl[u] = hash64(nk[u]) & h.hmask;
     }
-    a.badj[level][i] = res;
+    uint32_t ow[LINK_ILP];
+#pragma unroll
+    for (int u = 0; u < LINK_ILP; ++u) ow[u] = probe[u] ? h.occ[sl[u] >> 5] : 0u;
+    uint64_t k1[LINK_ILP];
+#pragma unroll
+    for (int u = 0; u < LINK_ILP; ++u) {
+      probe[u] = probe[u] && ((ow[u] >> (sl[u] & 31)) & 1u);  // a free first slot: the block does not exist
+      k1[u] = probe[u] ? h.keys[sl[u]] : KEY_EMPTY;
+    }
+#pragma unroll
+    for (int u = 0; u < LINK_ILP; ++u) {
+      if (!probe[u]) continue;
+      if (k1[u] == nk[u]) {
+        res[u] = h.rank[sl[u]];
+      } else {  // the first slot holds another block: walk on (rare)
+        const int s2 = bhash_find_from(h, nk[u], (sl[u] + 1) & h.hmask);
+        if (s2 >= 0) res[u] = h.rank[s2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LINK_ILP; ++u)
+      if (i0 + u * 256 < total) badj[i0 + u * 256] = res[u];
   }
 }
 

@@ -1202,7 +1202,7 @@ int sps_forward_metrics_n(sps_ctx *c, const float *batch, int64_t ld, int64_t n_
 }
 
 #if defined(SPS_FE_TRACE)
-static int g_maps_geom[8];
+static int g_maps_geom[8], g_link_geom[8];
 #endif
 static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, float vs, float *scores,
                         const ForwardOpts &fo, void *stream) {
@@ -1276,7 +1276,12 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
   {
     int co[NLV + 1] = {0};
-    for (int l = 0; l < NLV; ++l) co[l + 1] = co[l] + grid_for(((cap >> 3) >> (2 * l)) * 81, 256, 8192);
+    // chunk i = level NLV - 1 - i (coarsest first); a workgroup resolves 256 * LINK_ILP entries per step
+    for (int i = 0; i < NLV; ++i) co[i + 1] = co[i] + grid_for(((cap >> 3) >> (2 * (NLV - 1 - i))) * 81, 256 * LINK_ILP, 2048);
+#if defined(SPS_FE_TRACE)
+    g_link_geom[0] = gb;
+    for (int l = 0; l <= NLV; ++l) g_link_geom[1 + l] = co[l];
+#endif
     if (no_merge & 2) {
       hipLaunchKernelGGL(k_link_adj, dim3(4 * gb), dim3(256), 0, st, pa, gb, co[1], co[2], co[3], co[4], co[5]);
       hipLaunchKernelGGL(k_link_adj, dim3(co[NLV]), dim3(256), 0, st, pa, 0, co[1], co[2], co[3], co[4], co[5]);
@@ -1921,6 +1926,12 @@ int sps_get_logits(sps_ctx *c, float *logits_dev) {
 int sps_debug_fe_trace(unsigned long long *host, int n) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_fe_trace), (size_t)n * 8 * sizeof(unsigned long long)));
+  return SPS_OK;
+}
+int sps_debug_link_trace(unsigned long long *host, int n, int *geom /* [0] gb, [1..6] chunk offsets */) {
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_link_trace), (size_t)n * 2 * sizeof(unsigned long long)));
+  for (int i = 0; i < 8; ++i) geom[i] = g_link_geom[i];
   return SPS_OK;
 }
 int sps_debug_maps_trace(unsigned long long *host, int n, int *geom /* [0] nchunk, [1..6] chunk_off */) {

@@ -55,3 +55,17 @@ for pos, sl in enumerate((0, 1, 2)):     # launch order of the time slices
         show(f"nbr3 level {l} slice {sl}", range(pos * nchunk + co[l], pos * nchunk + co[l + 1]))
 for f in range(4):
     show(f"stride maps {f}->{f+1}", range(3 * nchunk + co[f], 3 * nchunk + co[f + 1]))
+
+buf = (C.c_ulonglong * (2 * n))()
+fn = _native.lib.sps_debug_link_trace
+fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+_native.check(fn(buf, n, geom))
+t = np.frombuffer(buf, dtype=np.uint64).reshape(n, 2).astype(np.int64)
+gb, co = geom[0], list(geom)[1:7]
+valid = t[:, 0] > 0
+t0 = t[valid, 0].min()
+print("k_link_adj: gb", gb, "adjacency chunk offsets", co, "traced workgroups", int(valid.sum()))
+for l in range(4):
+    show(f"links level {l}->{l+1}", range(l * gb, (l + 1) * gb))
+for i in range(5):
+    show(f"adjacency level {4 - i}", range(4 * gb + co[i], 4 * gb + co[i + 1]))
