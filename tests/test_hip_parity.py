@@ -607,3 +607,45 @@ def test_fused_forward_metrics_matches_separate_calls(net, params):
 def metrics_from_all(sums):
     from sps_amd.models.models import metrics_from_sums
     return metrics_from_sums(np.asarray(sums).sum(axis=0))
+
+@pytest.mark.timeout(600)
+def test_ranking_beyond_1024_workgroups(net):
+    """Single-pass block ranking (k_rank_points / k_rank_blocks_rows, grid_kernels.inc.h): a workgroup sums the aggregates
+    of ALL workgroups with a smaller ticket, 1 024 of them per look-back step.  1.3 M scattered points = 1 270 ranking
+    workgroups at level 0 AND (nearly every point its own block) at levels 1..4: voxel sets of every level against numpy on
+    the quantised coordinates, the inverse map, first-occurrence row order, run-to-run identical scores."""
+    rng = np.random.default_rng(3)
+    n = 1_300_000
+    xyz = (rng.random((n, 3), dtype=np.float32) * np.float32([400.0, 400.0, 40.0]) - np.float32([200.0, 200.0, 20.0]))
+    batch = np.zeros((n, 6), np.float32)
+    batch[:, 1:4] = xyz
+    batch[::3, 4] = 1.0                                    # two time indices, as a scan + submap batch
+    dev, s1 = run(net, batch)
+    cx = ctx()
+    counts = cx.level_counts()
+    q = np.floor(xyz / np.float32(VS)).astype(np.int64)    # f32 division, as models.py:21
+    t = batch[:, 4].astype(np.int64)
+    for lv in range(5):
+        c = q >> lv                                         # floor(c / 2^l): App. A.9
+        key = ((t * 4096 + (c[:, 2] + 2048)) * 8192 + (c[:, 1] + 4096)) * 8192 + (c[:, 0] + 4096)
+        uniq, first = np.unique(key, return_index=True)
+        assert counts[lv] == len(uniq), (lv, counts[lv], len(uniq))
+        if lv == 0:
+            key0, first0 = key, first
+    from sps_amd import _native
+    inv = torch.empty(n, dtype=torch.int64, device="cuda")
+    _native.check(_native.lib.sps_get_inverse(cx.handle, inv.data_ptr()))
+    inv = inv.cpu().numpy()
+    assert inv.min() == 0 and inv.max() == counts[0] - 1
+    rep = np.full(counts[0], -1, np.int64)
+    rep[inv] = key0                                          # one key per row ...
+    np.testing.assert_array_equal(rep[inv], key0)           # ... and every point of a row has it
+    assert len(np.unique(rep)) == counts[0]
+    vox = get_voxels(0, counts[0])                           # [b, x, y, z, t] per row
+    np.testing.assert_array_equal(vox[inv[:2000], 1:4], q[:2000])
+    # rows are block-contiguous with the blocks in first-occurrence order: the first point's voxel lives in block 0
+    assert inv[0] < 64
+    s1 = s1.clone()
+    _, s2 = run(net, batch)
+    assert torch.equal(s1, s2) and bool(torch.isfinite(s1).all())
+    cx.check_errors(0)
