@@ -28,7 +28,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 import sps.datasets.blt_dataset as datasets  # noqa: E402
 import sps.models.models as models  # noqa: E402
-from sps_amd import synthetic  # noqa: E402
+from sps_amd import scalars, synthetic  # noqa: E402
 
 DEFAULT_CONFIG_PATH = "./config/config.yaml"
 LOG_DIR = "./tb_logs"
@@ -116,6 +116,10 @@ def main(config, n_synth, max_epochs, out, host_items):
         torch.save({"epoch": epoch, "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                     "hyper_parameters": cfg, "val_loss": val_loss}, path)
 
+    # the scalars the reference logs through Lightning (models.py:74-75,80-81; LearningRateMonitor, TensorBoardLogger:
+    # train.py:38,46-50) -> <out>/<ID>/version_<n>/metrics.csv; device tensors are only read at the end of an epoch
+    slog = scalars.ScalarLog(out, cfg["EXPERIMENT"]["ID"]) if rank == 0 else None
+    global_step = 0
     best = float("inf")
     for epoch in range(epochs):
         model.train()
@@ -134,6 +138,10 @@ def main(config, n_synth, max_epochs, out, host_items):
             out_["loss"].backward()
             optimizer.step()
             losses.append(out_["loss"].detach())
+            if slog is not None:
+                slog.log(epoch, global_step, train_loss=losses[-1], train_r2=out_["val_r2"].detach(),
+                         **{"lr-Adam": optimizer.param_groups[0]["lr"]})
+            global_step += 1
         train_loss = float(torch.stack(losses).mean()) if losses else float("nan")
         model.eval()
         if world > 1:
@@ -149,6 +157,8 @@ def main(config, n_synth, max_epochs, out, host_items):
                 v = model.validation_step(batch.to(dev, non_blocking=True), i)
                 vl.append(v["val_loss"])
                 vr.append(v["val_r2"])
+                if slog is not None:
+                    slog.log(epoch, global_step, val_loss=v["val_loss"], val_r2=v["val_r2"])
         scheduler.step()
         # sticky device errors of the epoch's forwards (coordinate range, a level with a single row under train-mode BatchNorm)
         # surface here: one synchronisation per epoch, not per step
@@ -170,6 +180,8 @@ def main(config, n_synth, max_epochs, out, host_items):
         if rank == 0:
             print(f"epoch {epoch:03d}  train_loss {train_loss:.5f}  val_loss {val_loss:.5f}  val_r2 {val_r2:.4f}  "
                   f"lr {optimizer.param_groups[0]['lr']:.2e}  {len(losses) * world / max(time.time() - t0, 1e-9):.1f} steps/s")
+        if slog is not None:
+            slog.flush()
         save(os.path.join(ckpt_dir, "last.ckpt"), epoch, val_loss)
         if val_loss < best:
             best = val_loss

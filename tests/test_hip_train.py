@@ -117,6 +117,15 @@ def test_train_cli_writes_a_checkpoint_predict_cli_loads(tmp_path):
     ck = os.path.join(str(tmp_path), "BLT", "checkpoints", "last.ckpt")
     sd = torch.load(ck, map_location="cpu", weights_only=False)["state_dict"]
     assert "model.MinkUNet.block5.0.conv1.kernel" in sd and int(sd["model.MinkUNet.bn0.bn.num_batches_tracked"]) == 12
+    # the scalars the reference logs per step (models.py:74-75,80-81, LearningRateMonitor) in <out>/<ID>/version_0/metrics.csv
+    import csv
+    rows = list(csv.DictReader(open(os.path.join(str(tmp_path), "BLT", "version_0", "metrics.csv"))))
+    assert {"epoch", "step", "train_loss", "train_r2", "lr-Adam", "val_loss", "val_r2"} <= set(rows[0])
+    tr = [r for r in rows if r["train_loss"]]
+    assert len(tr) == 12 and [int(r["step"]) for r in tr] == list(range(12)) and {r["epoch"] for r in tr} == {"0", "1"}
+    assert all(np.isfinite(float(r["train_loss"])) and float(r["lr-Adam"]) > 0 for r in tr)
+    assert float(tr[-1]["lr-Adam"]) < float(tr[0]["lr-Adam"])             # StepLR: one decay between the two epochs
+    assert any(r["val_loss"] for r in rows)
     r = subprocess.run([sys.executable, os.path.join(root, "scripts", "predict.py"), "-w", ck, "--synthetic", "2",
                         "-c", os.path.join(root, "config", "config.yaml")], capture_output=True, text=True, timeout=600, cwd=root, env=env)
     assert r.returncode == 0, r.stderr[-2000:]

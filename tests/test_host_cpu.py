@@ -286,3 +286,21 @@ def test_hostplace_parses_cpulists_and_never_raises():
     assert hostplace._parse_cpulist("") == set()
     info = hostplace.bind_to_gpu_numa(0)            # no GPU / no sysfs entry here: a note, not an exception
     assert info["bound"] is False and set(info) >= {"pci", "numa_node", "cpus_before", "cpus_after", "bound"}
+
+
+def test_scalar_log_writes_lightning_csv_layout(tmp_path):
+    """sps_amd/scalars.py: the per-step scalars of the reference's loggers (models.py:74-75,80-81; train.py:38,46-50) in
+    <root>/<name>/version_<n>/metrics.csv; tensors are only read at flush()."""
+    import csv
+    from sps_amd.scalars import ScalarLog
+    log = ScalarLog(str(tmp_path), "BLT")
+    log.log(0, 0, train_loss=torch.tensor(0.5), train_r2=-1.0, **{"lr-Adam": 7e-5})
+    log.log(0, 1, val_loss=torch.tensor(0.25), val_r2=0.1)
+    assert not os.path.exists(log.path)
+    log.flush()
+    log.log(1, 1, train_loss=0.125, train_r2=0.0, **{"lr-Adam": 6.9e-5})
+    log.flush()
+    rows = list(csv.DictReader(open(log.path)))
+    assert list(rows[0]) == ["epoch", "step", "train_loss", "train_r2", "lr-Adam", "val_loss", "val_r2"]
+    assert [r["train_loss"] for r in rows] == ["0.5", "", "0.125"] and rows[1]["val_loss"] == "0.25" and rows[2]["epoch"] == "1"
+    assert log.dir.endswith("version_0") and ScalarLog(str(tmp_path), "BLT").dir.endswith("version_1")
