@@ -31,39 +31,60 @@ __device__ inline void metrics_body(float *__restrict__ scores, const float *__r
   // addresses -- 4.7 ms per step at batch = 4
   const int seg = (((n + nb - 1) / nb) + (int)blockDim.x - 1) / (int)blockDim.x * (int)blockDim.x;
   const int p_end = min(n, (bid + 1) * seg);
-  for (int p = bid * seg + (int)threadIdx.x; p < p_end; p += (int)blockDim.x) {
-    float s;
-    if (SLICE) {
-      const int vr = aborted ? -1 : inv[p];
-      s = vr >= 0 ? 1.0f / (1.0f + expf(-logits[vr])) : __builtin_nanf("");
-      scores[p] = s;
-    }
-    const float *row = m.batch + (size_t)p * m.ld;
-    if (row[4] != 1.0f) continue;  // scan rows only (t == 1)
-    const int bi = (int)row[0];
-    if (bi < 0 || bi >= m.n_batches) continue;
-    if (bi != b) {
-      if (b >= 0) {
+  // four points per thread and step: the loads of a phase (inverse map, then logit + batch row) are independent -- a thread's
+  // walk is a chain of dependent round trips, five steps of it were most of this kernel's 11 us
+  constexpr int ILP = 4;
+  for (int p0 = bid * seg + (int)threadIdx.x; p0 < p_end; p0 += ILP * (int)blockDim.x) {
+    int vr[ILP];
+    float sc[ILP], r0[ILP], r4[ILP], r5[ILP];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (v[j] != 0.0) atomicAdd(&m.acc[b * 8 + j], v[j]);
-          v[j] = 0.0;
-        }
-      }
-      b = bi;
+    for (int u = 0; u < ILP; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      vr[u] = (SLICE && !aborted && p < p_end) ? inv[p] : -1;
     }
-    if (!SLICE) s = scores[p];
-    const float g = row[5];
-    const int pred = s < m.eps ? 0 : 1, gt = g < m.eps ? 0 : 1;
-    const double d = (double)s - (double)g;
-    v[0] += 1;
-    v[1] += (gt == 1 && pred == 1);
-    v[2] += (gt == 0 && pred == 1);
-    v[3] += (gt == 1 && pred == 0);
-    v[4] += (gt == 0 && pred == 0);
-    v[5] += d * d;
-    v[6] += g;
-    v[7] += (double)g * (double)g;
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      const bool in = p < p_end;
+      if (SLICE) sc[u] = vr[u] >= 0 ? logits[vr[u]] : 0.f;
+      else sc[u] = in ? scores[p] : 0.f;
+      const float *row = m.batch + (size_t)(in ? p : 0) * m.ld;
+      r0[u] = row[0], r4[u] = in ? row[4] : 0.f, r5[u] = row[5];
+    }
+#pragma unroll
+    for (int u = 0; u < ILP; ++u) {
+      const int p = p0 + u * (int)blockDim.x;
+      if (p >= p_end) continue;
+      float s = sc[u];
+      if (SLICE) {
+        s = vr[u] >= 0 ? 1.0f / (1.0f + expf(-s)) : __builtin_nanf("");
+        scores[p] = s;
+      }
+      if (r4[u] != 1.0f) continue;  // scan rows only (t == 1)
+      const int bi = (int)r0[u];
+      if (bi < 0 || bi >= m.n_batches) continue;
+      if (bi != b) {
+        if (b >= 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (v[j] != 0.0) atomicAdd(&m.acc[b * 8 + j], v[j]);
+            v[j] = 0.0;
+          }
+        }
+        b = bi;
+      }
+      const float g = r5[u];
+      const int pred = s < m.eps ? 0 : 1, gt = g < m.eps ? 0 : 1;
+      const double d = (double)s - (double)g;
+      v[0] += 1;
+      v[1] += (gt == 1 && pred == 1);
+      v[2] += (gt == 0 && pred == 1);
+      v[3] += (gt == 1 && pred == 0);
+      v[4] += (gt == 0 && pred == 0);
+      v[5] += d * d;
+      v[6] += g;
+      v[7] += (double)g * (double)g;
+    }
   }
   // workgroup reduction when all its threads ended on the same batch index (the common case)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

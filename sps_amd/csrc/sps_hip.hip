@@ -1386,7 +1386,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     // slice + sigmoid and the hash clean-up, one launch
     // (with fused metrics the slice part is a persistent grid: few workgroups, register accumulation)
     const MetricsArgs mt{coords, ld, fo.eps, fo.n_batches, fo.metrics_out};
-    const int gst = fo.metrics_out ? grid_for(n, 1024, 128) : gs;
+    const int gst = fo.metrics_out ? grid_for(n, 1024, 256) : gs;  // (one step of 4 points per thread at 150 k points)
     hipLaunchKernelGGL(k_tail, dim3((unsigned)(gst + gbc * NLV)), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores, gst,
                        pa, gbc, mt);
   }
