@@ -249,11 +249,10 @@ __device__ inline int2 block_exclusive_scan2(int v0, int v1, int2 *wave_off, int
 // the workgroup's (first rank, number of first occurrences); false when the workgroup has no sources
 #if defined(SPS_FE_TRACE)  // DIAGNOSTIC build only (tools/fe_trace.py): wall-clock stamps (100 MHz) of the ranking workgroups
 __device__ unsigned long long g_fe_trace[8 * 4096];
-#define FE_STAMP(k) do { if (threadIdx.x == 0) g_fe_trace[8 * ((l == 0 ? 0 : 1024) + (FE_WG)) + (k)] = wall_clock64(); } while (0)
+#define FE_STAMP(kernel, k) do { if (threadIdx.x == 0) g_fe_trace[8 * ((kernel) * 1024 + blockIdx.x) + (k)] = wall_clock64(); } while (0)
 #else
-#define FE_STAMP(k) do { } while (0)
+#define FE_STAMP(kernel, k) do { } while (0)
 #endif
-#define FE_WG blockIdx.x
 struct Ranked {
   int flag, slot, rank, base;
   unsigned long long mask;
@@ -263,11 +262,11 @@ struct Ranked {
 // Every thread takes ITEMS consecutive sources (ranks follow the source order).
 template <int ITEMS>
 __device__ inline bool rank_pass(const PyramidArgs &a, int l, int n, Ranked &o, int *lds, int2 *wave_off, int *sh_id) {
-  FE_STAMP(0);
+  FE_STAMP(l != 0, 0);
   if (threadIdx.x == 0) *sh_id = atomicAdd(&a.counts[TICKET + l], 1);
   __syncthreads();
   const int id = *sh_id;
-  FE_STAMP(1);
+  FE_STAMP(l != 0, 1);
   constexpr int PER_WG = SCAN_BLOCK * ITEMS;
   const int nwg = (n + PER_WG - 1) / PER_WG;
   if (id >= nwg) return false;  // (every larger id leaves too: nobody waits for this workgroup)
@@ -306,9 +305,9 @@ __device__ inline bool rank_pass(const PyramidArgs &a, int l, int n, Ranked &o, 
   const int2 loc = block_exclusive_scan2(nf, nv, wave_off, tot);
   unsigned long long *agg = a.agg + (size_t)l * a.agg_stride;
   if (threadIdx.x == 0) __hip_atomic_store(agg + id, agg_pack(a.gen, tot.x, tot.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  FE_STAMP(2);
+  FE_STAMP(l != 0, 2);
   const int2 base = scan_lookback(agg, id, a.gen, lds, a.err);
-  FE_STAMP(3);
+  FE_STAMP(l != 0, 3);
   int r = base.x + loc.x, vb = base.y + loc.y;
   o.flag = 0;
   o.wg_rank0 = base.x, o.wg_blocks = tot.x;
@@ -353,8 +352,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_rank_points(PyramidArgs a, int n
   const int n = a.n_dev ? min(n0, *a.n_dev) : n0;
   Ranked k;
   if (!rank_pass<1>(a, 0, n, k, lds, wave_off, &sh_id)) return;
-  const int l = 0;
-  FE_STAMP(4);
+  FE_STAMP(0, 4);
   uint32_t tb = 0u;
   if (k.flag) {
     const uint64_t key = k.key;
@@ -372,8 +370,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_rank_points(PyramidArgs a, int n
   }
   const int nb = min(k.wg_blocks, a.bcapl[0] - k.wg_rank0);  // (blocks beyond the capacity have no arrays: the forward aborts)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  FE_STAMP(5);
-  {
+  FE_STAMP(0, 5);
   const int l = 1 + (wave & 3);
   for (int j0 = (wave >> 2) * 64; j0 < nb; j0 += 256) {
     const int j = j0 + lane;
@@ -405,9 +402,10 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_rank_points(PyramidArgs a, int n
     const int sl = wave_run_insert(a.h[l], pkey, ok, (uint32_t)pm, (uint32_t)(pm >> 32), r);
     if (ok) a.sslot[l][r] = sl;
   }
-  }
+#if defined(SPS_FE_TRACE)
   __syncthreads();
-  FE_STAMP(6);
+  FE_STAMP(0, 6);
+#endif
 }
 
 // levels 1..4 (sources = the level-0 blocks) ranked in one launch: workgroups [0, 4 gsb) rank (level 1 + b / gsb; the ids
@@ -427,13 +425,11 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_rank_blocks_rows(PyramidArgs a, 
     if (((int)blockIdx.x % gsb) * (SCAN_BLOCK * RANK_ITEMS) >= nblk) return;
     Ranked k;
     rank_pass<RANK_ITEMS>(a, 1 + (int)blockIdx.x / gsb, nblk, k, lds, wave_off, &sh_id);
-    const int l = 1;
-    FE_STAMP(4);
+    FE_STAMP(1, 4);
     return;
   }
   if (a.counts[ABORT]) return;  // level 0 overflowed: ranks and row bases are incomplete
-  const int l = 1;
-  FE_STAMP(0);
+  FE_STAMP(1, 0);
   const int n = a.n_dev ? min(n0, *a.n_dev) : n0;
   const int p = ((int)blockIdx.x - 4 * gsb) * SCAN_BLOCK + (int)threadIdx.x;
   if (p >= n) return;
@@ -448,7 +444,7 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_rank_blocks_rows(PyramidArgs a, 
     a.vbit[0][row] = (unsigned char)bit;
   }
   inv[p] = row;
-  FE_STAMP(6);
+  FE_STAMP(1, 6);
 }
 
 // blockIdx.y = l in 0..3.  (a) parent / child block links between level l and l+1 (one hash probe per
