@@ -3,11 +3,17 @@
 #   bench lines (default, driver protocol, serial, configs 3 and 4), rocprofv3 kernel stats (serial and pipelined),
 #   HBM traffic from separate FETCH_SIZE / WRITE_SIZE passes, SQ / TA / TCP counters per conv layer, training-step and
 #   online-filter timings.
+# The HBM traffic passes run first, so that the bench lines of the set carry the traffic measured on this very build.
 # usage: gpurun -- bash tools/collect_evidence.sh <tag>
 tag=${1:-round2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag; mkdir -p $o
-python3 bench.py > $o/bench.json 2> $o/bench.err
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $o/pmc_$ctr -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2> $o/bench.err
+done
+python3 tools/traffic_pmc.py $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/traffic.json > $o/traffic_summary.txt
+cp $o/traffic.json profiles/traffic.json   # (on the GPU box: the bench lines below then carry this build's `roofline.traffic`)
+python3 bench.py > $o/bench.json 2>> $o/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_driver_protocol.json 2>> $o/bench.err
 python3 bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline > $o/bench_serial_1stream.json 2>> $o/bench.err
 python3 bench.py --config 3 --steps 150 --warmup 20 > $o/bench_config3.json 2>> $o/bench.err
@@ -18,10 +24,6 @@ cp $(ls $o/prof_serial/*/*kernel_stats.csv | head -1) $o/kernel_stats.csv
 cp $(ls $o/prof_pipelined/*/*kernel_stats.csv | head -1) $o/kernel_stats_pipelined.csv
 python3 tools/kernel_table.py $o/prof_serial > $o/kernel_table.txt
 python3 tools/overlap.py $(ls $o/prof_pipelined/*/*kernel_trace.csv | head -1) $(ls $o/prof_serial/*/*kernel_trace.csv | head -1) > $o/overlap.txt
-for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $o/pmc_$ctr -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
-done
-python3 tools/traffic_pmc.py $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/traffic.json > $o/traffic_summary.txt
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $o/pmc_a -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $o/pmc_b -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
 python3 tools/pmc_table.py $o/pmc_a $o/pmc_b > $o/pmc_conv_layers.txt 2>> $o/bench.err
