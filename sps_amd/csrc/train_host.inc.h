@@ -44,11 +44,7 @@ struct sps_train {
   float *gpool = nullptr;                  // gradients of the feature buffers (one allocation, zeroed per backward)
   size_t gpool_bytes = 0;
   float *r_p[9] = {}, *r_g[9] = {};        // BN'd 1x1 downsample branch (the residual operand) of block i (2..8)
-  float *dz = nullptr, *dz2 = nullptr;     // scratch: gradient wrt a raw conv output [cap, 64], double-buffered (see side)
-  // the weight gradients run on a stream of their own: nothing but the optimiser waits for them, and the chain BN backward ->
-  // data gradient -> BN backward of the layer below is made of short latency-bound launches that leave the GPU to them
-  hipStream_t side = nullptr;
-  hipEvent_t ev_dz[2] = {nullptr, nullptr}, ev_w[2] = {nullptr, nullptr};  // dz buffer b written / consumed by its weight gradient
+  float *dz = nullptr;                     // scratch: gradient wrt a raw conv output [cap, 64]
   float *slab = nullptr;
   size_t slab_floats = 0;
   double *bn_part = nullptr, *bn_bpart = nullptr, *fin_part = nullptr;
@@ -69,16 +65,6 @@ struct sps_train {
 namespace {
 
 void train_free(sps_train *t) {
-  if (t->side) {
-    (void)hipStreamSynchronize(t->side);
-    (void)hipStreamDestroy(t->side);
-    t->side = nullptr;
-    for (int b = 0; b < 2; ++b) {
-      (void)hipEventDestroy(t->ev_dz[b]);
-      (void)hipEventDestroy(t->ev_w[b]);
-      t->ev_dz[b] = t->ev_w[b] = nullptr;
-    }
-  }
   for (void *p : t->allocs) (void)hipFree(p);
   t->allocs.clear();
   t->cap = 0;
@@ -164,12 +150,6 @@ int train_reserve(sps_ctx *c) {
     TALLOC(t->r_p[b], float, (size_t)cap * rcols[b]);
   }
   TALLOC(t->dz, float, (size_t)cap * 64);
-  TALLOC(t->dz2, float, (size_t)cap * 64);
-  HIP_TRY(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
-  for (int b = 0; b < 2; ++b) {
-    HIP_TRY(hipEventCreateWithFlags(&t->ev_dz[b], hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&t->ev_w[b], hipEventDisableTiming));
-  }
   t->slab_floats = (size_t)81 * 24 * 16 * 256;  // K * (MT * NT <= 24) * nchunk (<= 16) tiles of 16 x 16
   TALLOC(t->slab, float, t->slab_floats);
   TALLOC(t->bn_part, double, (size_t)s.bns.size() * BN_WG * 2 * BN_MAXC);
@@ -532,9 +512,7 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
                      b8o.ld, t->fin_part);
   hipLaunchKernelGGL(k_final_bwd_reduce, dim3(1), dim3(64), 0, st, t->fin_part, t->grad + fs.w_off, t->grad + s.bias_off);
   const auto ops = train_ops(c);
-  hipStream_t sw = t->side;  // weight gradients
-  int li = 0;                // layer counter: dz buffer li & 1
-  for (int oi = (int)ops.size() - 1; oi >= 0; --oi, ++li) {
+  for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
     const TOp &op = ops[oi];
     const int ci = s.find_conv(op.name);
     const ConvSpec &cs = s.convs[ci];
@@ -543,12 +521,8 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
     const int lo = op.out.level;
     const float *z = t->z[ci];
     const float *fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
-    const int db = li & 1;
-    float *dzb = db ? t->dz2 : t->dz;
     if (!vec4_ok(op.out.g, op.out.ld) || (op.res.g && !vec4_ok(op.res.g, op.res.ld)))
       return fail(SPS_ERR_INVALID, "training BatchNorm gradients must be 16-byte aligned (%s)", op.name);
-    // this layer's dZ goes to the buffer the weight gradient of two layers up read
-    if (li >= 2) HIP_TRY(hipStreamWaitEvent(st, t->ev_w[db], 0));
     // BN (+ ReLU, + residual) backward: dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, op.out.g, op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout,
                        c->counts + lo, cs.cout, fin, t->bn_bpart);
@@ -556,42 +530,31 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
                        t->grad + bn.off + bn.c);
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 2048)), dim3(256), 0, st, op.out.g,
                        op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, fin, t->bn_bfin,
-                       t->blob + bn.off, dzb, cs.cout, op.res.g, op.res.ld);
-    // fork: the weight gradient of this layer (reads dZ and the layer's input activations, writes its own slice of t->grad;
-    // the wgrad slab is only touched on that stream, whose launches run in order)
-    HIP_TRY(hipEventRecord(t->ev_dz[db], st));
-    HIP_TRY(hipStreamWaitEvent(sw, t->ev_dz[db], 0));
+                       t->blob + bn.off, t->dz, cs.cout, op.res.g, op.res.ld);
     int rc = SPS_OK;
     if (op.kind == T_CONV0) {
-      hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, sw, c->counts + 0, c->lv[0].view(), dzb, 8, 0.5f, t->c0part);
-      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(125), dim3(256), 0, sw, t->c0part, C0_WG, t->grad + cs.w_off);
-      HIP_TRY(hipEventRecord(t->ev_w[db], sw));
+      hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
+      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(125), dim3(256), 0, st, t->c0part, C0_WG, t->grad + cs.w_off);
       continue;  // the input feature is a constant: no data gradient
     }
     // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated
     if (op.kind == T_UP) {
-      rc = wgrad_launch(c, sw, T_UP, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dzb, cs.cout, t->grad + cs.w_off);
+      rc = wgrad_launch(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
       if (rc != SPS_OK) return rc;
-      HIP_TRY(hipEventRecord(t->ev_w[db], sw));
       // y[child] = x[parent] W[oct]  =>  dx[parent] += sum over children dy[child] W[oct]^T : a gather over the `down` table
-      rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dzb, cs.cout, op.in.g, op.in.ld, true);
+      rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     } else if (op.kind == T_DOWN) {
-      rc = wgrad_launch(c, sw, T_DOWN, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dzb, cs.cout, t->grad + cs.w_off);
+      rc = wgrad_launch(c, st, T_DOWN, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
       if (rc != SPS_OK) return rc;
-      HIP_TRY(hipEventRecord(t->ev_w[db], sw));
       // z[parent] = sum over children x[child] W[oct]  =>  dx[child] += dz[parent] W[oct]^T : parent-stationary scatter
-      rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dzb, cs.cout, op.in.g, op.in.ld, true);
+      rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     } else {
-      rc = wgrad_launch(c, sw, op.kind, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dzb, cs.cout, t->grad + cs.w_off);
+      rc = wgrad_launch(c, st, op.kind, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
       if (rc != SPS_OK) return rc;
-      HIP_TRY(hipEventRecord(t->ev_w[db], sw));
-      rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dzb, cs.cout, op.in.g, op.in.ld, true);
+      rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     }
     if (rc != SPS_OK) return rc;
   }
-  // join: every weight gradient is in t->grad (the last two layers' events cover the stream: its launches run in order)
-  if (li >= 1) HIP_TRY(hipStreamWaitEvent(st, t->ev_w[(li - 1) & 1], 0));
-  if (li >= 2) HIP_TRY(hipStreamWaitEvent(st, t->ev_w[(li - 2) & 1], 0));
   HIP_TRY(hipMemcpyAsync(grad_dev, t->grad, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
   HIP_TRY(hipGetLastError());
   return SPS_OK;
