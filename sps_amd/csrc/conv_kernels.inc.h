@@ -1062,9 +1062,9 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
 // conv0p1s1 (5x5x5x1, 1 -> 8, minkunet.py:55-62) fused with its kernel map.  The input feature is
 // the constant 0.5 (models.py:22; mean of 0.5s, App. A.4), so only the PRESENCE of each of the 125
 // neighbours matters: out[u] = sum_{k present} 0.5 * W[k], k ascending (App. A.8), then BN + ReLU.
-// One wave = one 16-row tile.  Lane group q fetches the occupancy of the (dy,dz) runs q, q+4, ...
-// (the five dx neighbours of a run live in two adjacent blocks whose masks give five presence bits;
-// all loads of a lane are independent: two round trips in total), the 125-bit presence maps of the
+// One wave = one 16-row tile.  Lane group q fetches the two x-adjacent blocks of ONE of the four (y, z) block pairs the
+// window touches (two round trips in total) and derives the presence bits of the (dy, dz) runs inside them (the five dx
+// neighbours of a run are five bits of the two masks), the 125-bit presence maps of the
 // four lane groups are OR-ed with two shuffles, and the convolution is 32 MFMAs with
 // A[row][k] = present ? 0.5 : 0 and B[k][n] = W[k][0][n] from LDS.  No neighbour table is materialised.
 __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_out, LevelView L,
@@ -1106,37 +1106,39 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
 #endif
       const int bit = L.vbit[u];
       const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
-      const int bo_lo = px < 2 ? -1 : 0;  // the dx run [px-2, px+2] touches blocks bo_lo and bo_lo + 1
-      const int *adj = L.badj + (size_t)blk * 81;
-      // two batches (4 + 3 runs) keep the kernel at 64 VGPRs = 8 waves per SIMD: one round for ~7k tiles
+      // The 5x5x5 window of a voxel touches exactly two blocks per axis (offsets lo, lo + 1 with lo = -1 for p < 2, else 0):
+      // 8 blocks.  Lane group q fetches the two x-neighbours of the (y, z) block pair it owns -- 2 adjacency entries + 2 masks
+      // per lane instead of 14 + 14 when every (dy, dz) run fetched its own -- and walks the runs that fall into them.
+      const int lx = px < 2 ? -1 : 0, ly = py < 2 ? -1 : 0, lz = pz < 2 ? -1 : 0;
+      const int ysel = q & 1, zsel = q >> 1;
+      const int *adj = L.badj + (size_t)blk * 81 + 27 + (lz + zsel + 1) * 9 + (ly + ysel + 1) * 3 + (lx + 1);
+      const int nb0 = adj[0], nb1 = adj[1];
+      const unsigned long long M0 = nb0 >= 0 ? L.bmask[nb0] : 0ull, M1 = nb1 >= 0 ? L.bmask[nb1] : 0ull;
+      const uint32_t m0lo = (uint32_t)M0, m0hi = (uint32_t)(M0 >> 32), m1lo = (uint32_t)M1, m1hi = (uint32_t)(M1 >> 32);
+      // rows ty of the window inside this group's y block: [ty0, ty1]; the same along z
+      const int ysplit = 4 * (ly + 1), zsplit = 4 * (lz + 1);
+      const int ty0 = ysel ? ysplit : py - 2, ty1 = ysel ? py + 2 : ysplit - 1;
+      const int tz0 = zsel ? zsplit : pz - 2, tz1 = zsel ? pz + 2 : zsplit - 1;
+      const int xs = px - 2 - 4 * lx;  // window bit j = presence at tx = 4 lx + j; the run starts at tx = px - 2
+#pragma unroll 1
+      for (int iz = 0; iz < 4; ++iz) {
+        const int tz = tz0 + iz;
+        const bool hiw = (tz & 2) != 0;  // bit 5 of the position: which half of the 64-bit mask
+        const uint32_t w0 = hiw ? m0hi : m0lo, w1 = hiw ? m1hi : m1lo;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        int nb0[4], nb1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = q + 4 * (4 * half + i);  // run index: dy = c % 5 - 2, dz = c / 5 - 2
-          const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
-          const int ad0 = 27 + ((tz >> 2) + 1) * 9 + ((ty >> 2) + 1) * 3 + 1 + bo_lo;
-          const bool on = c < 25;
-          nb0[i] = on ? adj[ad0] : -1;
-          nb1[i] = on ? adj[ad0 + 1] : -1;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = q + 4 * (4 * half + i);
-          const int ty = py + c % 5 - 2, tz = pz + c / 5 - 2;
-          const int sh = ((tz & 3) << 4) | ((ty & 3) << 2);
-          const uint32_t m0 = nb0[i] >= 0 ? (uint32_t)((L.bmask[nb0[i]] >> sh) & 0xFull) : 0u;
-          const uint32_t m1 = nb1[i] >= 0 ? (uint32_t)((L.bmask[nb1[i]] >> sh) & 0xFull) : 0u;
-          // window bit j = presence at tx = 4 * bo_lo + j; the run starts at tx = px - 2
-          const uint32_t pres = c < 25 ? (((m0 | (m1 << 4)) >> (px - 2 - 4 * bo_lo)) & 0x1Fu) : 0u;
-          const int k0 = 5 * c;  // k = 5 c + (dx + 2)
+        for (int iy = 0; iy < 4; ++iy) {
+          const int ty = ty0 + iy;
+          const bool on = tz <= tz1 && ty <= ty1;
+          const int sh = ((tz & 1) << 4) | ((ty & 3) << 2);
+          const uint32_t n0 = (w0 >> sh) & 0xFu, n1 = (w1 >> sh) & 0xFu;
+          const uint32_t pres = on ? (((n0 | (n1 << 4)) >> xs) & 0x1Fu) : 0u;
+          const int k0 = 5 * ((ty - py + 2) + 5 * (tz - pz + 2));  // k = 5 c + (dx + 2), c = (dy + 2) + 5 (dz + 2)
           const unsigned long long wide = (unsigned long long)pres << (k0 & 31);
-          const int w0 = (k0 >> 5) & 3;
-          bm[0] |= w0 == 0 ? (uint32_t)wide : 0u;
-          bm[1] |= w0 == 1 ? (uint32_t)wide : (w0 == 0 ? (uint32_t)(wide >> 32) : 0u);
-          bm[2] |= w0 == 2 ? (uint32_t)wide : (w0 == 1 ? (uint32_t)(wide >> 32) : 0u);
-          bm[3] |= w0 == 3 ? (uint32_t)wide : (w0 == 2 ? (uint32_t)(wide >> 32) : 0u);
+          const int wi = on ? (k0 >> 5) & 3 : 0;
+          bm[0] |= wi == 0 ? (uint32_t)wide : 0u;
+          bm[1] |= wi == 1 ? (uint32_t)wide : (wi == 0 ? (uint32_t)(wide >> 32) : 0u);
+          bm[2] |= wi == 2 ? (uint32_t)wide : (wi == 1 ? (uint32_t)(wide >> 32) : 0u);
+          bm[3] |= wi == 3 ? (uint32_t)wide : (wi == 2 ? (uint32_t)(wide >> 32) : 0u);
         }
       }
     }
