@@ -70,28 +70,65 @@ def stride_coords(coords: np.ndarray, ts: int) -> np.ndarray:
     return out
 
 
-def kernel_offsets(ksize, ts_xyz: int) -> np.ndarray:
-    """[K,4] offsets (dx,dy,dz,dt), x fastest / t slowest (App. A.6, A.7).
+# The ME conventions SURVEY App. A marks as unverifiable, as OPTIONS of the restatement (same names and values as
+# sps_amd/conventions.py, which this module deliberately does not import: the oracle realises an option in the
+# GEOMETRY it enumerates, the product as a permutation of the weight blob -- tests hold the two against each other).
+# ``cv`` below is any object with these attributes (or None = the defaults of App. A).
+CV_DEFAULTS = dict(offset_order="x_fastest", odd_kernel_sign="plus", even_kernel_order="ascending",
+                   transpose_index="same", lin_layout="in_out")
 
-    odd k: centred {-(k-1)/2..(k-1)/2}; even k: {0..k-1}; spatial offsets scaled by the
-    input tensor stride, temporal tensor stride is always 1 in this network.
+
+def cv_get(cv, name: str) -> str:
+    if cv is None:
+        return CV_DEFAULTS[name]
+    v = cv[name] if isinstance(cv, dict) else getattr(cv, name)
+    assert isinstance(v, str), (name, v)
+    return v
+
+
+def kernel_offsets(ksize, ts_xyz: int, cv=None) -> np.ndarray:
+    """[K,4] offsets (dx,dy,dz,dt) = in - out that weight slice k is applied to (App. A.6-A.8).
+
+    Defaults: x fastest / t slowest; odd k: centred {-(k-1)/2..(k-1)/2}; even k: {0..k-1}; spatial offsets scaled by
+    the input tensor stride, temporal tensor stride is always 1 in this network.  Options (``cv``): the enumeration
+    runs t fastest / x slowest; odd axes are walked from + to - (in = out - o_k); even axes from k-1 down to 0.
     """
     kx, ky, kz, kt = ksize
     strides = (ts_xyz, ts_xyz, ts_xyz, 1)
+    minus = cv_get(cv, "odd_kernel_sign") == "minus"
+    desc = cv_get(cv, "even_kernel_order") == "descending"
 
     def axis(k, s):
         if k % 2 == 1:
-            return [(i - k // 2) * s for i in range(k)]
-        return [i * s for i in range(k)]
+            a = [(i - k // 2) * s for i in range(k)]
+            return a[::-1] if minus else a
+        a = [i * s for i in range(k)]
+        return a[::-1] if desc else a
 
     ax = [axis(k, s) for k, s in zip((kx, ky, kz, kt), strides)]
     offs = []
-    for it in ax[3]:
-        for iz in ax[2]:
+    if cv_get(cv, "offset_order") == "x_fastest":
+        for it in ax[3]:
+            for iz in ax[2]:
+                for iy in ax[1]:
+                    for ix in ax[0]:
+                        offs.append((ix, iy, iz, it))
+    else:
+        for ix in ax[0]:
             for iy in ax[1]:
-                for ix in ax[0]:
-                    offs.append((ix, iy, iz, it))
+                for iz in ax[2]:
+                    for it in ax[3]:
+                        offs.append((ix, iy, iz, it))
     return np.asarray(offs, dtype=np.int64)
+
+
+def lin_kernel(W: np.ndarray, cin: int, cout: int, cv=None) -> np.ndarray:
+    """The [C_in, C_out] matrix of a ``kernel_size = 1`` convolution (App. A.11) from the stored tensor: 2-D
+    [C_in, C_out] (or 3-D [1, C_in, C_out]) by default, the memory read as [C_out, C_in] under lin_layout = out_in."""
+    W = np.asarray(W)
+    if cv_get(cv, "lin_layout") == "out_in":
+        return np.ascontiguousarray(W.reshape(cout, cin).T)
+    return W.reshape(cin, cout)
 
 
 class _CoordIndex:
@@ -255,7 +292,8 @@ class CoordinateManager:
     """Minimal stand-in for ME's coordinate manager: the coordinate set per tensor
     stride and the kernel maps, built lazily and cached for one forward pass."""
 
-    def __init__(self, coords_ts1: np.ndarray):
+    def __init__(self, coords_ts1: np.ndarray, cv=None):
+        self.cv = cv
         self.coords = {1: coords_ts1}
         self.parent = {}       # ts -> row of each ts-voxel's parent in the 2ts set
         self._k3 = {}
@@ -275,13 +313,13 @@ class CoordinateManager:
     def k3(self, ts):
         if ts not in self._k3:
             c = self.coords[ts]
-            self._k3[ts] = kernel_map(c, c, kernel_offsets((3, 3, 3, 3), ts))
+            self._k3[ts] = kernel_map(c, c, kernel_offsets((3, 3, 3, 3), ts, self.cv))
         return self._k3[ts]
 
     def k5(self):
         if self._k5 is None:
             c = self.coords[1]
-            self._k5 = kernel_map(c, c, kernel_offsets((5, 5, 5, 1), 1))
+            self._k5 = kernel_map(c, c, kernel_offsets((5, 5, 5, 1), 1, self.cv))
         return self._k5
 
     def kdown(self, ts):
@@ -290,7 +328,7 @@ class CoordinateManager:
         if ts not in self._kdown:
             self.ensure_stride(2 * ts)
             self._kdown[ts] = kernel_map(self.coords[ts], self.coords[2 * ts],
-                                         kernel_offsets((2, 2, 2, 1), ts))
+                                         kernel_offsets((2, 2, 2, 1), ts, self.cv))
         return self._kdown[ts]
 
 
@@ -308,17 +346,19 @@ def _basic_block(p, name, x, cm, ts):
     y = sparse_conv(y, n, cm.k3(ts), p[name + ".conv2.kernel"])
     y = _bn(p, name + ".norm2", y)
     if (name + ".downsample.0.kernel") in p:
-        r = (x @ p[name + ".downsample.0.kernel"]).astype(F32)
+        cout = p[name + ".conv1.kernel"].shape[2]
+        r = (x @ lin_kernel(p[name + ".downsample.0.kernel"], x.shape[1], cout, cm.cv)).astype(F32)
         r = _bn(p, name + ".downsample.1", r)
     else:
         r = x
     return relu(y + r)
 
 
-def unet_forward(p, coords_ts1: np.ndarray, feats: np.ndarray, keep=False):
+def unet_forward(p, coords_ts1: np.ndarray, feats: np.ndarray, keep=False, cv=None):
     """MinkUNetBase.forward (minkunet.py:161-219) on CustomMinkUNet widths.
-    Returns (logits [V1,1], CoordinateManager, intermediates dict if keep)."""
-    cm = CoordinateManager(coords_ts1)
+    Returns (logits [V1,1], CoordinateManager, intermediates dict if keep).  ``cv``: ME-convention options."""
+    cm = CoordinateManager(coords_ts1, cv)
+    mirrored = cv_get(cv, "transpose_index") == "mirrored"
     inter = {}
 
     def rec(name, v):
@@ -346,13 +386,15 @@ def unet_forward(p, coords_ts1: np.ndarray, feats: np.ndarray, keep=False):
     for i in range(4):
         fine = ts // 2
         km = cm.kdown(fine)
-        cur = sparse_conv(cur, len(cm.coords[fine]), km, p[ups[i] + ".kernel"], transpose=True)
+        Wup = p[ups[i] + ".kernel"]
+        cur = sparse_conv(cur, len(cm.coords[fine]), km, Wup[::-1] if mirrored else Wup, transpose=True)
         cur = relu(_bn(p, f"bntr{4 + i}", cur))
         ts = fine
         cur = np.concatenate([cur, skips[ts]], axis=1)          # ME.cat(out, skip)
         cur = rec(f"block{5 + i}", _basic_block(p, f"block{5 + i}.0", cur, cm, ts))
 
-    logits = (cur @ p["final.kernel"] + p["final.bias"]).astype(F32)
+    n_out = np.asarray(p["final.bias"]).size
+    logits = (cur @ lin_kernel(p["final.kernel"], cur.shape[1], n_out, cv) + np.asarray(p["final.bias"]).reshape(1, -1)).astype(F32)
     return logits, cm, inter
 
 
@@ -361,12 +403,12 @@ def sigmoid(x):
     return (F32(1.0) / (F32(1.0) + np.exp(-x))).astype(F32)
 
 
-def sps_forward(p, coordinates: np.ndarray, voxel_size: float, keep=False):
-    """SPSModel.forward (models.py:20-30): [N,5] float (b,x,y,z,t) -> scores [N]."""
+def sps_forward(p, coordinates: np.ndarray, voxel_size: float, keep=False, cv=None):
+    """SPSModel.forward (models.py:20-30): [N,5] float (b,x,y,z,t) -> scores [N].  ``cv``: ME-convention options."""
     q = quantize(coordinates, voxel_size)
     vox, inv = unique_first(q)
     feats = np.full((len(vox), 1), 0.5, dtype=F32)          # mean of 0.5's (App. A.4)
-    logits, cm, inter = unet_forward(p, vox, feats, keep=keep)
+    logits, cm, inter = unet_forward(p, vox, feats, keep=keep, cv=cv)
     scores = sigmoid(logits[inv, 0])                         # slice + sigmoid (A.15)
     info = {"voxels": vox, "inverse": inv, "logits": logits[:, 0], "cm": cm, "inter": inter}
     return scores, info
@@ -382,7 +424,7 @@ def voxel_mean(features: np.ndarray, inverse: np.ndarray, n_vox: int) -> np.ndar
     return (acc / np.maximum(cnt, 1).astype(F32)).astype(F32).reshape(-1, 1)
 
 
-def head_forward(p, coordinates: np.ndarray, voxel_size: float, features=None, keep=False):
+def head_forward(p, coordinates: np.ndarray, voxel_size: float, features=None, keep=False, cv=None):
     """The baseline heads on the same backbone: raw logits [N, out_channels] per point.
       * 4DMOS  (c_ws/src/mos4d/scripts/mos4d.py:17-32): constant 0.5 feature, 3-channel `final`, caller takes
         column 2;
@@ -393,7 +435,7 @@ def head_forward(p, coordinates: np.ndarray, voxel_size: float, features=None, k
         feats = np.full((len(vox), 1), 0.5, dtype=F32)
     else:
         feats = voxel_mean(np.asarray(features), inv, len(vox))
-    logits, cm, inter = unet_forward(p, vox, feats, keep=keep)
+    logits, cm, inter = unet_forward(p, vox, feats, keep=keep, cv=cv)
     info = {"voxels": vox, "inverse": inv, "logits": logits, "voxel_features": feats, "cm": cm, "inter": inter}
     return logits[inv], info
 

@@ -45,19 +45,28 @@ def _block(p, name, x, cm, ts, stats):
     y = torch.relu(_bn(p, name + ".norm1", _conv(x, n, cm.k3(ts), p[name + ".conv1.kernel"]), stats))
     y = _bn(p, name + ".norm2", _conv(y, n, cm.k3(ts), p[name + ".conv2.kernel"]), stats)
     if (name + ".downsample.0.kernel") in p:
-        r = _bn(p, name + ".downsample.1", x @ p[name + ".downsample.0.kernel"], stats)
+        r = _bn(p, name + ".downsample.1", x @ _lin(p[name + ".downsample.0.kernel"], x.shape[1], cm.cv), stats)
     else:
         r = x
     return torch.relu(y + r)
 
 
-def train_step(params: dict, batch: np.ndarray, voxel_size: float, dtype=torch.float64):
+def _lin(W, cin, cv):
+    """kernel_size = 1 kernel as a [C_in, C_out] matrix (O.lin_kernel, differentiable: a view of the stored tensor)."""
+    if O.cv_get(cv, "lin_layout") == "out_in":
+        return W.reshape(-1, cin).t()
+    return W.reshape(cin, -1)
+
+
+def train_step(params: dict, batch: np.ndarray, voxel_size: float, dtype=torch.float64, cv=None):
     """One common_step: returns (loss float, scores [N] numpy, grads dict name -> numpy, batch stats dict
-    bn name -> (mean, biased var, rows)).  ``batch`` rows are (b,x,y,z,t,label)."""
+    bn name -> (mean, biased var, rows)).  ``batch`` rows are (b,x,y,z,t,label).  ``cv``: ME-convention options
+    (oracle/sps_oracle.py); gradients come back in the layout the parameters were given in."""
     p = {k: torch.tensor(np.asarray(v), dtype=dtype, requires_grad=("running" not in k)) for k, v in params.items()}
     q = O.quantize(batch[:, :5], voxel_size)
     vox, inv = O.unique_first(q)
-    cm = O.CoordinateManager(vox)
+    cm = O.CoordinateManager(vox, cv)
+    mirrored = O.cv_get(cv, "transpose_index") == "mirrored"
     stats = {}
     feats = torch.full((len(vox), 1), 0.5, dtype=dtype)
     out = _conv(feats, len(vox), cm.k5(), p["conv0p1s1.kernel"])
@@ -73,12 +82,13 @@ def train_step(params: dict, batch: np.ndarray, voxel_size: float, dtype=torch.f
         skips[ts] = cur
     for i, name in enumerate(["convtr4p16s2", "convtr5p8s2", "convtr6p4s2", "convtr7p2s2"]):
         fine = ts // 2
-        cur = _conv(cur, len(cm.coords[fine]), cm.kdown(fine), p[name + ".kernel"], transpose=True)
+        Wup = p[name + ".kernel"]
+        cur = _conv(cur, len(cm.coords[fine]), cm.kdown(fine), torch.flip(Wup, dims=(0,)) if mirrored else Wup, transpose=True)
         cur = torch.relu(_bn(p, f"bntr{4 + i}", cur, stats))
         ts = fine
         cur = torch.cat([cur, skips[ts]], dim=1)
         cur = _block(p, f"block{5 + i}.0", cur, cm, ts, stats)
-    logits = cur @ p["final.kernel"] + p["final.bias"]
+    logits = cur @ _lin(p["final.kernel"], cur.shape[1], cv) + p["final.bias"]
     scores = torch.sigmoid(logits[torch.from_numpy(inv), 0])
     scan = torch.from_numpy(np.flatnonzero(batch[:, 4] == 1))
     gt = torch.tensor(batch[:, 5], dtype=dtype)

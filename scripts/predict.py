@@ -59,18 +59,24 @@ def batched(loader, k):
               help="Run inference on a specific sequence. Otherwise, test split from config is used.")
 @click.option("--config", "-c", type=str, default=DEFAULT_CONFIG_PATH, help="Path to the config file (.yaml)")
 @click.option("--synthetic", "n_synth", type=int, default=0, help="evaluate N synthetic scans instead of $DATA")
-@click.option("--batch-size", "-b", "batch_size", type=int, default=4,
-              help="scans per forward (batch column 0..b-1, BacchusModule.collate_fn layout).  The reference forces 1 "
-                   "(predict.py:50) because its predict_step pools the scan rows of a batch; here the metric sums are kept "
-                   "per batch index, so the printed per-scan means are the same for any value and 4 (BASELINE config 3) "
-                   "amortises the per-launch costs: ~15 %% more scans/s than 1")
+@click.option("--batch-size", "-b", "batch_size", type=int, default=1,
+              help="scans per forward (batch column 0..b-1, BacchusModule.collate_fn layout).  Default 1 = the reference "
+                   "(it forces BATCH_SIZE = 1, predict.py:50).  The metric sums are kept per batch index, so any value prints "
+                   "the same per-scan means up to the f32 summation order inside a forward (scores move by <= 2e-6: a label "
+                   "exactly at the threshold can flip); -b 4 (BASELINE config 3) is the opt-in throughput mode: ~15 %% more "
+                   "scans/s")
+@click.option("--me-conventions", "me_conventions", type=str, default=None,
+              help="MinkowskiEngine conventions the checkpoint follows, 'option=value,...' (sps_amd/conventions.py; "
+                   "tools/convention_probe.py finds them); default: MODEL.ME_CONVENTIONS of the config, else the canonical ones")
 @click.option("--streams", type=int, default=None, help="forwards in flight (HIP streams); default: the engine's")
 @click.option("--timing", is_flag=True, help="print scans/s of the evaluation loop (rank 0)")
 @click.option("--force-dist", is_flag=True, help="initialise the process group (RCCL) and all-gather the metric rows even at world size 1")
 @click.option("--host-items", is_flag=True, help="assemble the items on the host (DataLoader workers + scipy cKDTree, as the "
                                                  "reference does) instead of on the device")
-def main(weights, sequence, config, n_synth, batch_size, streams, timing, force_dist, host_items):
+def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams, timing, force_dist, host_items):
     cfg = yaml.safe_load(open(config))
+    if me_conventions:
+        cfg["MODEL"]["ME_CONVENTIONS"] = me_conventions
     if sequence:
         cfg["DATA"]["SPLIT"]["TEST"] = [sequence]
     print('Test seq: ', cfg["DATA"]["SPLIT"]["TEST"])

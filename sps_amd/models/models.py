@@ -21,7 +21,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
-from .. import _native
+from .. import _native, conventions
 from .minkunet import CustomMinkUNet
 
 _CONTEXTS: dict[tuple, "_native.Context"] = {}
@@ -53,12 +53,51 @@ class NativeBackboneModule(nn.Module):
     """Common part of the modules that own a ``self.MinkUNet`` parameter container and run it through
     libsps_hip.so: keeps the native weight blob of a (device, stream) context in sync with the parameters."""
 
-    def _init_backbone(self, out_channels: int) -> None:
+    def _init_backbone(self, out_channels: int, me_conventions=None) -> None:
         self.MinkUNet = CustomMinkUNet(in_channels=1, out_channels=out_channels, D=4)
         self._dev_weights = {}           # device index -> _native.Weights holding this module's current parameters
         self._blob = None                # host copy of the weight blob in the native layout
+        # which MinkowskiEngine conventions the parameters are written in (sps_amd/conventions.py: the ONE switch-point);
+        # the library computes in the canonical one, the blob is permuted where it is packed
+        self.me_conventions = conventions.parse(me_conventions)
+        self._blob_perm = {}
         # any load_state_dict that reaches the backbone (predict.py:58 or util.py:39) re-uploads
         self.MinkUNet.register_load_state_dict_post_hook(lambda module, incompatible: self._on_load_state_dict())
+        self.MinkUNet._register_load_state_dict_pre_hook(self._accept_lin_kernel_shapes, with_module=True)
+
+    def set_me_conventions(self, spec) -> None:
+        """Declare the ME conventions the current / future parameters follow (None = conventions.DEFAULT)."""
+        self.me_conventions = conventions.parse(spec)
+        self.mark_weights_dirty()
+        self._plan = None
+
+    @staticmethod
+    def _accept_lin_kernel_shapes(module, state_dict, prefix, *_):
+        """A ``kernel_size = 1`` kernel may arrive 3-D ``[1, C_in, C_out]`` or (lin_layout = out_in) as
+        ``[C_out, C_in]``: the stored MEMORY is kept, what it means is decided by ``me_conventions`` where the blob is packed."""
+        for name, p in module.named_parameters():
+            key = prefix + name
+            if name.endswith(".kernel") and p.dim() == 2 and key in state_dict:
+                t = state_dict[key]
+                if t.shape != p.shape and t.numel() == p.numel():
+                    state_dict[key] = t.reshape(p.shape)
+
+    def blob_permutation(self):
+        """perm with ``blob_internal = blob_as_stored[perm]`` (host int64 numpy) or None for the canonical conventions."""
+        cv = self.me_conventions
+        if cv.is_default:
+            return None
+        oc = self.MinkUNet.out_channels
+        perm = self._blob_perm.get((cv, oc))
+        if perm is None:
+            sd = self.MinkUNet.state_dict()
+            shapes = {}
+            for name, _, _ in _native.weight_layout(oc):
+                if name.endswith(".kernel"):
+                    sh = tuple(sd[name].shape)
+                    shapes[name] = sh if len(sh) == 3 else (1,) + sh
+            perm = self._blob_perm[(cv, oc)] = conventions.blob_permutation(_native.weight_layout(oc), shapes, cv)
+        return perm
 
     # ---- weights -> native blob ---------------------------------------------------------
     def _on_load_state_dict(self) -> None:
@@ -91,6 +130,9 @@ class NativeBackboneModule(nn.Module):
                     if t.numel() != numel:
                         raise ValueError(f"parameter {name} has {t.numel()} elements, the native layout expects {numel}")
                     blob[off: off + numel] = t.numpy()
+                perm = self.blob_permutation()
+                if perm is not None:     # the checkpoint's conventions -> the library's (conventions.py)
+                    blob = np.ascontiguousarray(blob[perm])
                 self._blob = blob
             w = self._dev_weights[device_index] = _native.Weights(device_index, blob.ctypes.data, blob.size, oc)
         return w
@@ -136,7 +178,8 @@ class _TrainForward(torch.autograd.Function):
             stream = torch.cuda.current_stream().cuda_stream
             ctx = get_context(dev.index or 0, stream)
             plan = module._train_plan(dev)          # parameters + BN buffers: views of one tensor in the native layout
-            blob = plan.flat
+            # non-canonical ME conventions: the library sees the permuted copy, the gradient goes back through the inverse
+            blob = plan.flat if plan.perm is None else plan.flat.index_select(0, plan.perm)
             n = coordinates.shape[0]
             scores = torch.empty(n, dtype=torch.float32, device=dev)
             stats = torch.zeros(plan.n_stats, dtype=torch.float32, device=dev)
@@ -144,20 +187,22 @@ class _TrainForward(torch.autograd.Function):
                               module.voxel_size, scores.data_ptr(), stats.data_ptr(), stream)
             generation = ctx.train_generation()     # the activations this node's backward needs live in the context
         fctx.save_for_backward(scores)
-        fctx.native = (ctx, [plan.span_of[id(p)] + (tuple(p.shape),) for p in params], blob.numel(), generation)
+        fctx.native = (ctx, [plan.span_of[id(p)] + (tuple(p.shape),) for p in params], blob.numel(), generation, plan.inv_perm)
         fctx.mark_non_differentiable(stats)
         return scores, stats
 
     @staticmethod
     def backward(fctx, dscores, _dstats):
         (scores,) = fctx.saved_tensors
-        ctx, spans, numel, generation = fctx.native
+        ctx, spans, numel, generation, inv_perm = fctx.native
         with torch.cuda.device(scores.device):
             stream = torch.cuda.current_stream().cuda_stream
             grad = torch.empty(numel, dtype=torch.float32, device=scores.device)
             d = dscores.to(torch.float32).contiguous()
             # fails (SpsError) if a later forward on this context overwrote the activations: no silently wrong gradients
             ctx.train_backward(d.data_ptr(), scores.data_ptr(), grad.data_ptr(), numel, stream, generation)
+            if inv_perm is not None:
+                grad = grad.index_select(0, inv_perm)
             # data-parallel training (one process per GPU, scripts/train.py under torchrun): the gradient of the whole
             # network is ONE flat tensor, so the ranks exchange it with a single all-reduce (RCCL over xGMI, 7.4 MB)
             # instead of one per parameter
@@ -172,7 +217,7 @@ class _TrainForward(torch.autograd.Function):
 
 class _TrainPlan:
     """What a training step needs from the module, computed once per placement of the module's tensors."""
-    __slots__ = ("flat", "checks", "params", "span_of", "n_stats", "run_idx", "stat_idx", "nbt")
+    __slots__ = ("flat", "checks", "params", "span_of", "n_stats", "run_idx", "stat_idx", "nbt", "perm", "inv_perm")
 
 
 class SPSModel(NativeBackboneModule):
@@ -255,6 +300,9 @@ class SPSModel(NativeBackboneModule):
         plan.run_idx = torch.cat(run).to(device)
         plan.stat_idx = torch.cat(stat).to(device)
         plan.nbt = nbt
+        perm = self.blob_permutation()
+        plan.perm = None if perm is None else torch.from_numpy(perm).to(device)
+        plan.inv_perm = None if perm is None else torch.from_numpy(conventions.inverse_permutation(perm)).to(device)
         self._plan = plan
         return plan
 
@@ -275,6 +323,10 @@ class SPSNet(nn.Module):
         super().__init__()
         self.hparams = hparams
         self.model = SPSModel(hparams["MODEL"]["VOXEL_SIZE"])
+        # optional, not in the reference's config.yaml: MODEL.ME_CONVENTIONS = {option: value} or "option=value,..."
+        # (sps_amd/conventions.py) for a checkpoint whose MinkowskiEngine build indexes its kernels differently
+        if hparams["MODEL"].get("ME_CONVENTIONS"):
+            self.model.set_me_conventions(hparams["MODEL"]["ME_CONVENTIONS"])
         self.save_vis = save_vis
         self.data_dir = str(os.environ.get("DATA"))
         self.test_seq = hparams["DATA"]["SPLIT"]["TEST"]

@@ -46,7 +46,12 @@ class PendingFilter:
         self._o.ctx.check_errors(self._stream.cuda_stream)           # SPS_ERR_RANGE etc. (NaN scores are never silently dropped)
         n_sub, n_scan_vox, _, n_keep = (int(x) for x in self._counts_host.tolist())
         e0, e1, e2 = self._ev
-        return FilterResult(self._filtered[:n_keep], self._scores[: self.n], n_scan_vox, n_sub,
+        predicted_scan_labels = self._scores[: self.n]
+        # sps_node.py:147 (same message): one score per scan point as received
+        assert len(predicted_scan_labels) == self.n, \
+            f"Predicted scans labels len ({len(predicted_scan_labels)}) does not equal scan len ({self.n})"
+        assert 0 <= n_keep <= self.n, f"filtered scan len ({n_keep}) exceeds scan len ({self.n})"
+        return FilterResult(self._filtered[:n_keep], predicted_scan_labels, n_scan_vox, n_sub,
                             time.time() - self._t0, e0.elapsed_time(e1) * 1e-3, e1.elapsed_time(e2) * 1e-3)
 
 
