@@ -109,7 +109,10 @@ int sps_ctx_set_weights(sps_ctx *ctx, sps_weights_handle *w);
  *   coords_dev : float32 rows (b,x,y,z,t,...) with row stride `ld` floats (ld >= 5)
  *   scores_dev : float32 [n]
  * Rows whose voxel does not fit the key range get score NaN and the call that next
- * synchronises (sps_metrics / sps_check) reports SPS_ERR_RANGE. */
+ * synchronises (sps_metrics / sps_check) reports SPS_ERR_RANGE.
+ * NOT capturable into a HIP graph: the single-pass ranking kernels tell the forwards of a context apart by a generation
+ * number that is a KERNEL ARGUMENT (host counter); a replayed graph would carry a frozen generation and match the previous
+ * replay's aggregates without waiting for them.  Every forward must be issued through these entry points. */
 int sps_forward(sps_ctx *ctx, const float *coords_dev, int64_t ld, int64_t n, float voxel_size,
                 float *scores_dev, void *stream);
 /* Synchronises `stream` and returns SPS_ERR_RANGE if any forward since the last check
@@ -311,6 +314,18 @@ int sps_get_tile_masks(sps_ctx *ctx, int which, uint32_t *masks_dev, int64_t *n_
 /* The 3x3x3x3 neighbour table of level `which` (0..4), int32 [81][V] compact; entries of (tile, k)
  * pairs whose tile-mask bit is clear are unspecified (never written, never read by the convolution). */
 int sps_get_nbr(sps_ctx *ctx, int which, int32_t *nbr_dev);
+/* A kernel map of the last forward as ME holds it (the set of (input row, output row) pairs per kernel offset; reached from
+ * /root/reference/src/sps/models/MinkowskiEngine/minkunet.py:162-217), exported as a dense int32 table [K][V_out] compact:
+ * out[k * V_out + u] = input row paired with output row u through offset k, or -1.
+ *   which = 0..4: 3x3x3x3 map of level which (K = 81, k = (dx+1) + 3(dy+1) + 9(dz+1) + 27(dt+1));
+ *   which = 5:    5x5x5x1 map of level 0 (K = 125; materialised for this call -- conv0 derives the same presence bits from the
+ *                 block tables without ever storing the map);
+ *   which = 6..9: stride-2 map into coarse level which - 5 (K = 8, k = dx + 2dy + 4dz; rows = coarse voxels, entries = fine
+ *                 rows; the transposed convolutions read the same table with the roles swapped).
+ * source = 0: the output-stationary neighbour / child table; source = 1 (which = 0..4 at the pair-exact levels): decoded from
+ * the RULEBOOK the pair-exact convolutions read; *n_entries (may be NULL) = number of pairs it holds (malformed or duplicate
+ * entries fail the call). */
+int sps_get_kernel_map(sps_ctx *ctx, int which, int source, int32_t *out_dev, int64_t *n_entries);
 /* Per-voxel logits of the last forward, float32 [V_0]. */
 int sps_get_logits(sps_ctx *ctx, float *logits_dev);
 /* Named intermediate feature maps: "out_p1","block1".."block8"; copies [V,C] row-major

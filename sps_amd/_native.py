@@ -94,6 +94,7 @@ def _load() -> C.CDLL:
         "sps_get_map_pairs": (i32, [vp, i32, C.POINTER(i64)]),
         "sps_get_tile_masks": (i32, [vp, i32, vp, C.POINTER(i64)]),
         "sps_get_nbr": (i32, [vp, i32, vp]),
+        "sps_get_kernel_map": (i32, [vp, i32, i32, vp, C.POINTER(i64)]),
         "sps_get_logits": (i32, [vp, vp]),
         "sps_get_feature": (i32, [vp, C.c_char_p, vp, C.POINTER(i64), C.POINTER(i64)]),
     }
@@ -118,7 +119,7 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_transform_points", "sps_filter_prepare", "sps_forward_n",
            "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_train_generation", "sps_train_backward_at", "sps_radius_grid_upload", "sps_radius_count",
            "sps_radius_fill", "sps_radius_grid_attach", "sps_radius_item", "sps_forward_metrics_n", "sps_level_counts", "sps_get_voxels",
-           "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_logits", "sps_get_feature"]
+           "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_kernel_map", "sps_get_logits", "sps_get_feature"]
 
 
 def check(rc: int) -> None:
@@ -330,6 +331,18 @@ class Context:
         out = (C.c_int64 * NUM_LEVELS)()
         check(lib.sps_level_counts(self.handle, out))
         return list(out)
+
+    def kernel_map(self, which: int, source: int = 0):
+        """Dense int32 [K, V_out] table of a kernel map of the last forward (include/sps_hip.h: sps_get_kernel_map), on the
+        device; with source = 1 also the number of pairs the rulebook holds."""
+        import torch
+        counts = self.level_counts()
+        level = which if which <= 4 else (0 if which == 5 else which - 5)
+        K = 81 if which <= 4 else (125 if which == 5 else 8)
+        out = torch.empty((K, counts[level]), dtype=torch.int32, device=f"cuda:{self.device}")
+        n = C.c_int64()
+        check(lib.sps_get_kernel_map(self.handle, which, source, out.data_ptr(), C.byref(n)))
+        return (out, n.value) if source == 1 else out
 
     def map_pairs(self, which: int):
         out = (C.c_int64 * 125)()

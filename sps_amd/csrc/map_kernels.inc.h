@@ -327,6 +327,43 @@ __global__ void k_count_pairs_rb(const uint32_t *__restrict__ rb_e, const unsign
   }
 }
 
+// Debug export of a kernel map as a dense table out[k * n + u] = input row of output row u through offset k, or -1
+// (sps_get_kernel_map): from a neighbour-style table (entries whose tile-mask bit is clear were never written: -1) ...
+__global__ void k_export_table(const int *__restrict__ nbr, int64_t ldn, int K, int slice_words, const int *__restrict__ n_ptr,
+                               const uint32_t *__restrict__ tmask, int *__restrict__ out) {
+  const int n = *n_ptr;
+  const int k = blockIdx.y;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x)
+    out[(size_t)k * n + u] = tile_mask_test(tmask, u, k, slice_words != 0) ? nbr[(size_t)k * ldn + u] : -1;
+}
+
+// ... or decoded from the RULEBOOK the pair-exact convolutions read (out pre-filled with -1; `entries` counts the decoded
+// pairs, `dups` the (offset, output row) slots that were written twice: must stay 0)
+__global__ void k_export_rulebook(const uint32_t *__restrict__ rb_e, const unsigned char *__restrict__ rb_k,
+                                  const int *__restrict__ rb_cnt, const int *__restrict__ n_ptr, int *__restrict__ out,
+                                  unsigned long long *__restrict__ entries) {
+  const int n = *n_ptr;
+  const int nst = (n + 63) >> 6;
+  const int64_t total = (int64_t)nst * 3 * PX_SEG_CH * 16;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 15);
+    const int64_t ch = i >> 4;
+    const int st = (int)(ch / (3 * PX_SEG_CH)), r = (int)(ch - (int64_t)st * (3 * PX_SEG_CH));
+    const int seg = r / PX_SEG_CH, lc = r - seg * PX_SEG_CH;
+    if (lc >= rb_cnt[(size_t)st * 4 + seg]) continue;
+    const uint32_t e = rb_e[((size_t)st * PX_CH_MAX + (size_t)seg * PX_SEG_CH + lc) * 16 + j];
+    if (e == PX_PAD) continue;
+    const int k = rb_k[(size_t)st * PX_KSTRIDE + seg * 112 + lc];
+    const int u = st * 64 + (int)(e & 63u);
+    atomicAdd(&entries[0], 1ull);
+    if (u >= n || k >= 81 || k / 27 != seg) {  // malformed entry
+      atomicAdd(&entries[1], 1ull);
+      continue;
+    }
+    if (atomicExch(&out[(size_t)k * n + u], (int)(e >> 6)) != -1) atomicAdd(&entries[1], 1ull);
+  }
+}
+
 __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slice_words, const int *__restrict__ n_ptr,
                               const uint32_t *__restrict__ tmask, unsigned long long *__restrict__ pairs) {
   const int n = *n_ptr;

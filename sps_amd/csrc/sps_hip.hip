@@ -1427,10 +1427,15 @@ int sps_profile_read(sps_ctx *c, int idx, char *name, int name_cap, float *ms) {
 }
 
 // sticky device error flags -> error code (after the caller has synchronised the stream that copied them)
+__global__ void k_err_clear(int *err, int bits) { atomicAnd(err, ~bits); }
+
+// One sticky bit is reported (and cleared) per synchronising call, most severe first; the others STAY set for the next call:
+// two users of one context (a training step and a device item loader) each get to see their own error.
 static int report_device_errors(sps_ctx *c, int e, hipStream_t st) {
   if (!e) return SPS_OK;
-  HIP_TRY(hipMemsetAsync(c->err, 0, sizeof(int), st));
-  if (e & 2) {
+  const int bit = (e & 2) ? 2 : (e & 16) ? 16 : (e & 8) ? 8 : (e & 1) ? 1 : (e & 4) ? 4 : e;
+  hipLaunchKernelGGL(k_err_clear, dim3(1), dim3(1), 0, st, c->err, bit);
+  if (bit == 2) {
     // a level outgrew its compact arrays: that forward was aborted (NaN scores).  Dense sizes from now on -- the next
     // forward re-allocates and cannot overflow; the caller re-issues the affected work
     c->compact = false;
@@ -1439,15 +1444,17 @@ static int report_device_errors(sps_ctx *c, int e, hipStream_t st) {
                                "sps_ctx_set_level_fractions): the forward was aborted and its scores are NaN; the context "
                                "has switched to full-size arenas, re-issue the forward");
   }
-  if (e & 16) return fail(SPS_ERR_HIP, "internal: a ranking workgroup waited for a predecessor that never published (results of that forward are invalid)");
-  if (e & 8)
+  if (bit == 16) return fail(SPS_ERR_HIP, "internal: a ranking workgroup waited for a predecessor that never published (results of that forward are invalid)");
+  if (bit == 8)
     return fail(SPS_ERR_INVALID, "train-mode BatchNorm: a level of the training forward had a single active row (Expected more "
                                  "than 1 value per channel when training)");
-  if (e & 4)
+  if (bit == 1)
+    return fail(SPS_ERR_RANGE,
+                "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");
+  if (bit == 4)
     return fail(SPS_ERR_ITEMCAP, "sps_radius_item: the item buffer is too small for the scan rows + the radius submap rows "
-                               "(the rows beyond it were dropped): pass a larger row_cap");
-  return fail(SPS_ERR_RANGE,
-              "a coordinate is outside the voxel-key range (|x,y,z| < 131072 voxels, t in [-16,15], b in [0,30])");
+                                 "(the rows beyond it were dropped): pass a larger row_cap");
+  return fail(SPS_ERR_HIP, "internal: unknown device error bits 0x%x", e);
 }
 
 int sps_check(sps_ctx *c, void *stream) {
@@ -1787,7 +1794,7 @@ int sps_radius_item(sps_ctx *c, const void *scan_dev, int in_f64, int64_t ld, in
   if (n > SPS_MAX_POINTS || row_cap > SPS_MAX_POINTS) return fail(SPS_ERR_INVALID, "too many points");
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
-  if (n > c->item_cap) {  // scratch of the scans: grows once per context (first use / a larger scan)
+  if (!c->item_base || n > c->item_cap) {  // scratch of the scans: grows once per context (first use, also an empty first scan / a larger scan)
     HIP_TRY(hipDeviceSynchronize());
     for (void *p : {(void *)c->item_counts, (void *)c->item_offsets, (void *)c->item_bsum, (void *)c->item_base}) (void)hipFree(p);
     c->item_counts = c->item_offsets = c->item_bsum = c->item_base = nullptr;
@@ -1910,6 +1917,52 @@ int sps_get_nbr(sps_ctx *c, int which, int32_t *nbr_dev) {
   for (int k = 0; k < 81; ++k)
     HIP_TRY(hipMemcpy(nbr_dev + (size_t)k * cnt[which], c->lv[which].nbr3 + (size_t)k * c->capl[which],
                       (size_t)cnt[which] * sizeof(int), hipMemcpyDeviceToDevice));
+  return SPS_OK;
+}
+
+int sps_get_kernel_map(sps_ctx *c, int which, int source, int32_t *out_dev, int64_t *n_entries) {
+  if (!c || !out_dev || which < 0 || which > 9 || source < 0 || source > 1) return fail(SPS_ERR_INVALID, "bad arguments");
+  int64_t cnt[SPS_NUM_LEVELS];
+  int rc = sps_level_counts(c, cnt);
+  if (rc != SPS_OK) return rc;
+  const int level = which <= 4 ? which : (which == 5 ? 0 : which - 5);  // level of the OUTPUT rows
+  const int K = which <= 4 ? 81 : (which == 5 ? 125 : 8);
+  const int64_t n = cnt[level];
+  if (n_entries) *n_entries = -1;
+  if (n == 0) return SPS_OK;
+  if (source == 1) {
+    if (which > 4) return fail(SPS_ERR_INVALID, "only the 3x3x3x3 maps have a rulebook");
+    const Level &L = c->lv[which];
+    if (!L.rb_e) return fail(SPS_ERR_INVALID, "level %d keeps no rulebook (its layers run output-stationary)", which);
+    HIP_TRY(hipMemset(out_dev, 0xFF, (size_t)K * n * sizeof(int)));
+    HIP_TRY(hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_export_rulebook, dim3(1024), dim3(256), 0, 0, L.rb_e, L.rb_k, L.rb_cnt, c->counts + which, out_dev, c->pairs);
+    unsigned long long h[2];
+    HIP_TRY(hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost));
+    if (h[1]) return fail(SPS_ERR_INVALID, "rulebook of level %d: %llu malformed or duplicate entries", which, h[1]);
+    if (n_entries) *n_entries = (int64_t)h[0];
+    return SPS_OK;
+  }
+  const int *tab = nullptr;
+  const uint32_t *tm = nullptr;
+  int64_t ldn = 0;
+  if (which <= 4) {
+    if (!c->lv[which].nbr3)
+      return fail(SPS_ERR_INVALID, "an inference-only context keeps no neighbour table at level %d (source 1 = its rulebook)", which);
+    tab = c->lv[which].nbr3, tm = c->lv[which].tm3, ldn = c->capl[which];
+  } else if (which == 5) {
+    // debug only: materialise the 5x5x5x1 table from the (still valid) block tables -- conv0 itself never stores it
+    if (!c->nbr5) ALLOC(c->nbr5, int, 125 * c->cap);
+    HIP_TRY(hipMemset(c->tm5, 0, (size_t)(c->cap / 16) * 4 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_build_nbr5, dim3(grid_for(c->cap, 256, 1024), 25), dim3(256), 0, 0, c->counts + 0, c->lv[0].view(),
+                       c->nbr5, c->cap, c->tm5);
+    tab = c->nbr5, tm = c->tm5, ldn = c->cap;
+  } else {
+    tab = c->lv[level].down, tm = c->lv[level].tmdown, ldn = c->capl[level];
+  }
+  hipLaunchKernelGGL(k_export_table, dim3(grid_for(n, 256, 1024), K), dim3(256), 0, 0, tab, ldn, K, which <= 4 ? 1 : 0,
+                     c->counts + level, tm, out_dev);
+  HIP_TRY(hipDeviceSynchronize());
   return SPS_OK;
 }
 

@@ -89,8 +89,12 @@ class ScanEngine:
                 self.reset_table(table_rows)
             if stage_cols and max_rows:
                 for k in range(len(self.streams)):
-                    self._stage[k] = [torch.empty((int(max_rows), int(stage_cols)), dtype=torch.float32, device=self.device)
-                                      for _ in range(2)]
+                    # allocated ON the stream that uses them: when _to_device drops a pair for a larger one, the caching
+                    # allocator returns the blocks to that stream's pool (no other stream can be handed memory a forward
+                    # in flight on stream k still reads)
+                    with torch.cuda.stream(self.streams[k]):
+                        self._stage[k] = [torch.empty((int(max_rows), int(stage_cols)), dtype=torch.float32, device=self.device)
+                                          for _ in range(2)]
             torch.cuda.synchronize(self.device)
 
     def reset_table(self, rows: int) -> None:

@@ -109,6 +109,49 @@ def test_radius_item_overflow_is_reported():
     del sub
 
 
+def test_empty_scan_as_the_first_item_of_a_fresh_context_and_sticky_errors():
+    """(i) An empty scan as the very first item a context sees: the scratch of the scans (where the item's row base is
+    written) is allocated on first use whatever n is -- it used to be a device write through a null pointer.
+    (ii) One sticky error is reported per synchronising call and only THAT bit is cleared: an item overflow and an
+    out-of-range coordinate on the same context both surface, in two calls."""
+    from sps_amd import _native
+    from sps_amd._native import ERR_ITEMCAP, ERR_RANGE, SpsError
+    from sps_amd.datasets.blt_dataset import DeviceRadiusSubmap
+    pc_map, scans = _scene()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        st = stream.cuda_stream
+        cx = _native.Context(0)                                    # fresh: no item scratch yet
+        sub = DeviceRadiusSubmap(pc_map[:, :3], VS, ctx=cx)
+        rows = torch.full((64, 6), -7.0, dtype=torch.float32, device="cuda")
+        nrows = torch.full((4,), 99, dtype=torch.int32, device="cuda")
+        cx.radius_item(0, True, 4, 0, 0.0, None, rows.data_ptr(), 6, rows.shape[0], nrows.data_ptr(), st)
+        stream.synchronize()
+        cx.check_errors(st)
+        assert int(nrows[0]) == 0 and (rows == -7.0).all()
+        # (ii) overflow the item buffer, then an out-of-range forward on the same context
+        n = len(scans[0])
+        small = torch.empty((n + 10, 6), dtype=torch.float32, device="cuda")
+        dev = torch.from_numpy(scans[0]).cuda()
+        cx.radius_item(dev.data_ptr(), True, 4, n, 0.0, None, small.data_ptr(), 6, small.shape[0], nrows.data_ptr(), st)
+        net = net_from_params(O.random_params(seed=0)).cuda().eval().freeze()
+        net.model._sync_weights(cx)
+        far = torch.tensor([[0, 2.0e4, 0, 0, 1], [0, 0.1, 0.2, 0.3, 1]], dtype=torch.float32, device="cuda")   # 20 km: outside the key range
+        sc = torch.empty(2, dtype=torch.float32, device="cuda")
+        cx.forward(far.data_ptr(), 5, 2, VS, sc.data_ptr(), st)
+        stream.synchronize()
+        assert torch.isnan(sc[0]) and not torch.isnan(sc[1])
+        codes = []
+        for _ in range(2):
+            with pytest.raises(SpsError) as e:
+                cx.check_errors(st)
+            codes.append(e.value.code)
+        assert sorted(codes) == sorted([ERR_RANGE, ERR_ITEMCAP]), codes
+        cx.check_errors(st)                                        # both reported, both cleared
+        del sub
+        cx.close()
+
+
 @pytest.fixture(scope="module")
 def net():
     params = straddle_params(O.random_params(seed=0), synthetic.small_scene(seed=11, n_scan=2500))

@@ -40,11 +40,15 @@ def run(net, batch_np):
     return dev, scores
 
 
-def get_voxels(level, count):
+def get_voxels_of(c, level, count):
     out = torch.empty((count, 5), dtype=torch.int32, device="cuda")
     from sps_amd import _native
-    _native.check(_native.lib.sps_get_voxels(ctx().handle, level, out.data_ptr()))
+    _native.check(_native.lib.sps_get_voxels(c.handle, level, out.data_ptr()))
     return out.cpu().numpy()
+
+
+def get_voxels(level, count):
+    return get_voxels_of(ctx(), level, count)
 
 
 def get_feature(name):
@@ -73,6 +77,47 @@ def match_rows(got: np.ndarray, want: np.ndarray) -> np.ndarray:
     return perm
 
 
+def oracle_table(kmap, n_out):
+    """ME-style kernel map (per offset the (in, out) index lists) -> dense [K, n_out] table of input rows, -1 = no pair;
+    asserts that an output row occurs at most once per offset."""
+    tab = np.full((len(kmap), n_out), -1, np.int64)
+    for k, (i, o) in enumerate(kmap):
+        assert len(np.unique(o)) == len(o)
+        tab[k, o] = i
+    return tab
+
+
+def assert_same_pairs(got, want, perm_out, perm_in, what):
+    """``got`` [K, V_out] in the HIP path's row numbering == ``want`` in the oracle's: per offset the SET of (in, out) pairs."""
+    got = np.asarray(got, np.int64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert got.min(initial=-1) >= -1 and got.max(initial=-1) < len(perm_in), what
+    mapped = np.where(got >= 0, perm_in[np.maximum(got, 0)], -1)
+    np.testing.assert_array_equal(mapped, want[:, perm_out], err_msg=what)
+
+
+def check_kernel_maps(cm, perm, counts):
+    """Row a10 as pair SETS: the 3x3x3x3 map of every level from the neighbour table AND (levels that run pair-exact) decoded
+    from the rulebook the convolutions read, the 5x5x5x1 map, and the four stride-2 maps (= the transposed convolutions' maps
+    with in / out swapped) against cm.k3 / k5 / kdown of the oracle."""
+    c = ctx()
+    n_pairs = 0
+    for l in range(5):
+        want = oracle_table(cm.k3(1 << l), counts[l])
+        assert_same_pairs(c.kernel_map(l, 0).cpu().numpy(), want, perm[l], perm[l], f"3^4 neighbour table, level {l}")
+        if l <= 1:
+            tab, n_entries = c.kernel_map(l, 1)
+            assert n_entries == int((want >= 0).sum()), f"rulebook level {l}: {n_entries} pairs, oracle {(want >= 0).sum()}"
+            assert_same_pairs(tab.cpu().numpy(), want, perm[l], perm[l], f"3^4 rulebook, level {l}")
+        n_pairs += int((want >= 0).sum())
+    assert_same_pairs(c.kernel_map(5, 0).cpu().numpy(), oracle_table(cm.k5(), counts[0]), perm[0], perm[0], "5x5x5x1 map")
+    for l in range(1, 5):
+        want = oracle_table(cm.kdown(1 << (l - 1)), counts[l])
+        assert int((want >= 0).sum()) == counts[l - 1]             # every fine voxel has exactly one parent and one offset
+        assert_same_pairs(c.kernel_map(5 + l, 0).cpu().numpy(), want, perm[l], perm[l - 1], f"stride map into level {l}")
+    return n_pairs
+
+
 def check_full(net, params, batch, tol=2e-4, both_classes=False):
     dev, scores = run(net, batch)
     ref, info = O.sps_forward(params, batch[:, :5], VS, keep=True)
@@ -96,6 +141,7 @@ def check_full(net, params, batch, tol=2e-4, both_classes=False):
         want = [len(i) for i, _ in cm.k3(1 << l)]
         assert ctx().map_pairs(l) == want, f"3^4 map level {l}"
     assert ctx().map_pairs(5) == [len(i) for i, _ in cm.k5()]
+    check_kernel_maps(cm, perm, counts)                           # ... and as pair sets, offset by offset
     # --- features
     tap_level = {"out_p1": 0, "block1": 1, "block2": 2, "block3": 3, "block4": 4, "block5": 3, "block6": 2,
                  "block7": 1, "block8": 0}
@@ -403,6 +449,45 @@ def test_config3_batch4_full_size(net, params):
         single = net(torch.from_numpy(scan).cuda()).cpu().numpy()
         np.testing.assert_allclose(sg[rows], single, rtol=0, atol=5e-6)
         assert metrics_from_sums(sums[b])["dIoU"] > 0
+
+
+@pytest.mark.timeout(900)
+def test_config2_kernel_maps_as_pair_sets(net):
+    """BASELINE config 2 at spec size: all ten kernel maps (+ the rulebooks of the pair-exact levels) as sets of (in, out)
+    pairs per offset against the numpy oracle's coordinate manager; also from an inference-only context (the product
+    loop's kind: ScanEngine), where the rulebook is all that exists at levels 0-1."""
+    batch = synthetic.make_scene(scan_seed=1)["batch"]
+    assert len(batch) > 140_000
+    run(net, batch)
+    counts = ctx().level_counts()
+    vox, inv = O.unique_first(O.quantize(batch[:, :5], VS))
+    cm = O.CoordinateManager(vox)
+    for ts in (2, 4, 8, 16):
+        cm.ensure_stride(ts)
+    perm = [match_rows(get_voxels(l, counts[l]), cm.coords[1 << l]) for l in range(5)]
+    n_pairs = check_kernel_maps(cm, perm, counts)
+    assert n_pairs > 2_500_000                                    # (3^4 maps alone; + 2.7 M pairs of the 5x5x5x1 map)
+    from sps_amd import _native
+    from sps_amd.models.models import get_context
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        c2 = get_context(0, st.cuda_stream)
+        c2.set_inference_only(True)
+        try:
+            dev = torch.from_numpy(batch).cuda()
+            net(dev)
+            st.synchronize()
+            assert c2.level_counts() == counts
+            with pytest.raises(_native.SpsError):
+                c2.kernel_map(0, 0)                                # no neighbour table at the pair-exact levels
+            perm2 = [match_rows(get_voxels_of(c2, l, counts[l]), cm.coords[1 << l]) for l in range(2)]
+            for l in range(2):
+                tab, n_entries = c2.kernel_map(l, 1)
+                want = oracle_table(cm.k3(1 << l), counts[l])
+                assert n_entries == int((want >= 0).sum())
+                assert_same_pairs(tab.cpu().numpy(), want, perm2[l], perm2[l], f"inference-only rulebook, level {l}")
+        finally:
+            c2.set_inference_only(False)
 
 
 @pytest.mark.timeout(900)

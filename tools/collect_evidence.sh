@@ -8,11 +8,17 @@
 tag=${1:-round2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 o=gpurun_out/$tag; mkdir -p $o
+: > $o/bench.err
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $o/pmc_$ctr -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2> $o/bench.err
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $o/pmc_$ctr -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
 done
-python3 tools/traffic_pmc.py $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/traffic.json > $o/traffic_summary.txt
-cp $o/traffic.json profiles/traffic.json   # (on the GPU box: the bench lines below then carry this build's `roofline.traffic`)
+# the tracked profiles/traffic.json (what `roofline.traffic` of every later bench line reports) is replaced only by a
+# complete measurement of this build: both passes present and the derivation successful
+if python3 tools/traffic_pmc.py $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/traffic.json > $o/traffic_summary.txt 2>> $o/bench.err && [ -s $o/traffic.json ]; then
+  cp $o/traffic.json profiles/traffic.json   # (on the GPU box: the bench lines below then carry this build's `roofline.traffic`)
+else
+  echo "traffic_pmc.py failed: profiles/traffic.json left as it was" | tee -a $o/bench.err
+fi
 python3 bench.py > $o/bench.json 2>> $o/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_driver_protocol.json 2>> $o/bench.err
 python3 bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline > $o/bench_serial_1stream.json 2>> $o/bench.err
