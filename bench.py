@@ -313,7 +313,7 @@ def main():
     work = roofline.algorithmic_work(n_points, V, pairs3, pairs5)
     t_step = gpu_ms * 1e-3 / K
     achieved = work["bytes"] / t_step / 1e9
-    stages, dom, dom_bytes = [], None, None
+    stages, dom, dom_bytes, classes = [], None, None, {}
     if not args.no_stages:
         # per-stage breakdown (separate serial pass with one hipEvent after every kernel stage, on the launch stream)
         ctx.profile_enable(True)
@@ -325,6 +325,7 @@ def main():
                 if name not in acc:
                     order.append(name)
                 acc[name] = acc.get(name, 0.0) + ms / reps
+        kernel_of = dict(zip([n for n, _ in ctx.profile_read()], ctx.profile_kernels()))
         ctx.profile_enable(False)
         for name in order:
             pl = work["per_layer"].get(name)
@@ -337,6 +338,15 @@ def main():
                 entry.update(alg_bytes=pl["bytes"], alg_gbs=round(gbs, 1), hbm_frac=round(hf, 4),
                              alg_tflops=round(tf, 2), mfma_f32_frac=round(mf, 4),
                              roof_bound="hbm" if hf >= mf else "mfma", roof_frac=round(max(hf, mf), 4))
+            # the stages grouped by the kernel they launch -- what `rocprofv3 --stats` aggregates by name
+            kern = kernel_of.get(name) or "(memset)"
+            entry["kernel"] = kern
+            cl = classes.setdefault(kern, {"us": 0.0, "launches": 0, "bytes": 0, "flops": 0})
+            cl["us"] += acc[name] * 1e3
+            cl["launches"] += len(kern.split("+")) if kern != "(memset)" else 0
+            if pl:
+                cl["bytes"] += pl["bytes"]
+                cl["flops"] += pl["flops"]
             stages.append(entry)
         layer_stages = [s for s in stages if s["stage"] in work["per_layer"]]
         dom = max(layer_stages, key=lambda s: s["ms"])                      # longest kernel stage
@@ -362,6 +372,22 @@ def main():
         "dominant_kernel": dom, "largest_traffic_kernel": dom_bytes if stages else None,
         "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
     }
+    if classes:
+        # flat scalars (nested values do not survive the driver's parser): the kernel CLASS with the most time per step in the
+        # serial pass (hipEvents around every launch), with its own roofline fractions
+        dk, dv = max(classes.items(), key=lambda kv: kv[1]["us"])
+        t = dv["us"] * 1e-6
+        roof.update(
+            dominant_kernel_name=dk, dominant_kernel_us=round(dv["us"], 2),
+            dominant_kernel_launches_per_step=dv["launches"],
+            dominant_kernel_alg_bytes=dv["bytes"], dominant_kernel_alg_flops=dv["flops"],
+            dominant_kernel_hbm_frac=round(dv["bytes"] / t / 1e9 / roofline.HBM_PEAK_GBS, 5) if dv["bytes"] else None,
+            dominant_kernel_mfma_frac=round(dv["flops"] / t / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5) if dv["flops"] else None,
+            serial_kernel_us_per_step=round(sum(v["us"] for v in classes.values()), 2),
+            launches_per_step=sum(v["launches"] for v in classes.values()),
+            kernel_classes="; ".join(f"{k}: {v['us']:.1f} us / {v['launches']} launches"
+                                     for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["us"])),
+        )
 
     # ---- CPU baseline + parity: the oracle's C restatement on this box's host cores (checker only) ----
     cpu = None
@@ -433,6 +459,8 @@ def main():
                    "compact_arenas": eng.compact},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,
         "mean_confusion": confusion, "inputs": inputs, "resident_inputs": resident, "h2d_inclusive": h2d,
+        "resident_value": resident["value"],
+        "dist_backend": (dist.get_backend() if dist is not None else None), "dist_world_size": (dist.get_world_size() if dist is not None else 1),
         "host_cores": os.cpu_count(), "host_placement": placement,
         "host_issue_ms_per_step": round(host_issue_ms, 4),
     }

@@ -294,6 +294,9 @@ int sps_train_backward_at(sps_ctx *ctx, int64_t generation, const float *dscores
 int sps_profile_enable(sps_ctx *ctx, int on);
 int sps_profile_count(sps_ctx *ctx);
 int sps_profile_read(sps_ctx *ctx, int idx, char *name, int name_cap, float *ms);
+/* The kernel (class) stage idx launched, e.g. "k_conv_px", "k_conv<3x3x3x3, levels 2-4>", "k_upconv", "k_maps": lets
+ * bench.py aggregate the stages per kernel the way `rocprofv3 --stats` does. */
+int sps_profile_kernel(sps_ctx *ctx, int idx, char *name, int name_cap);
 
 /* ---- introspection (parity tests; all synchronise) ----------------------------------- */
 /* Number of active voxels at each tensor stride of the last forward. */

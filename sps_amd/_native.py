@@ -69,6 +69,7 @@ def _load() -> C.CDLL:
         "sps_profile_enable": (i32, [vp, i32]),
         "sps_profile_count": (i32, [vp]),
         "sps_profile_read": (i32, [vp, i32, C.c_char_p, i32, C.POINTER(f32)]),
+        "sps_profile_kernel": (i32, [vp, i32, C.c_char_p, i32]),
         "sps_map_upload": (i32, [vp, vp, i64, i64, f32, vp]),
         "sps_map_upload_voxels": (i32, [vp, vp, i64, i64, vp]),
         "sps_submap_voxel": (i32, [vp, vp, i64, i64, vp, C.POINTER(i64), C.POINTER(i64), vp]),
@@ -115,7 +116,7 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_weights_create", "sps_weights_destroy", "sps_ctx_set_weights",
            "sps_forward", "sps_forward_metrics", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
            "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
-           "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_map_upload", "sps_map_upload_voxels",
+           "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_profile_kernel", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_transform_points", "sps_filter_prepare", "sps_forward_n",
            "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_train_generation", "sps_train_backward_at", "sps_radius_grid_upload", "sps_radius_count",
            "sps_radius_fill", "sps_radius_grid_attach", "sps_radius_item", "sps_forward_metrics_n", "sps_level_counts", "sps_get_voxels",
@@ -267,6 +268,15 @@ class Context:
         for i in range(lib.sps_profile_count(self.handle)):
             check(lib.sps_profile_read(self.handle, i, buf, 96, C.byref(ms)))
             out.append((buf.value.decode(), ms.value))
+        return out
+
+    def profile_kernels(self):
+        """[kernel class] of the stages profile_read() lists (sps_profile_kernel)."""
+        buf = C.create_string_buffer(128)
+        out = []
+        for i in range(lib.sps_profile_count(self.handle)):
+            check(lib.sps_profile_kernel(self.handle, i, buf, 128))
+            out.append(buf.value.decode())
         return out
 
     def map_upload(self, xyz_ptr: int, ld: int, m: int, ds: float, stream: int):

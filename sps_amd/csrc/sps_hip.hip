@@ -281,6 +281,8 @@ struct sps_ctx {
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
   std::vector<std::string> prof_names;
+  std::vector<std::string> prof_kernels;  // kernel(s) the stage launched (sps_profile_kernel)
+  const char *last_kernel = "";          // set next to every launch of forward_impl / run_conv
   size_t prof_n = 0;
   // variant-A radius grid (device copies owned by the ctx)
   RadiusGrid rg{};
@@ -724,6 +726,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       to.counts = c->counts;
       gto = NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS;
     }
+    c->last_kernel = c->cur_vfeat ? "k_conv0_feat" : "k_conv0_fused";
     if (c->cur_vfeat) {
       hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)(g0 + gto)), dim3(256), 0, st, a.n_out,
                          c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, c->cur_vfeat, a.out, a.ldo, to, g0);
@@ -747,6 +750,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       if (gu < 64) gu = 64;
       if (gu > 8192) gu = 8192;
       const dim3 gr((unsigned)gu);
+      c->last_kernel = "k_upconv";
       if (a.NT == 1)
         hipLaunchKernelGGL((k_upconv<1>), gr, dim3(256), 0, st, a);
       else if (a.NT == 2)
@@ -770,6 +774,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     a.px_order = TILE_ORDER != 0 ? c->lv[cc.level_out].px_order : nullptr;
     a.rb_supertiles = (int)(c->capl[cc.level_out] / 64);
     const int key = cs.cin * 100 + (cs.cout == 8 ? 10 : 0) + (cc.fin ? 2 : (ds ? 1 : 0));
+    c->last_kernel = "k_conv_px";
 #define SPS_PX_LAUNCH(CIN_, C8_, DS_, FIN_)                                                                  \
   do {                                                                                                       \
     if (cc.level_out == 0)                                                                                   \
@@ -820,6 +825,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     return fail(SPS_ERR_INVALID, "%s has no pair-exact instantiation and the inference-only context keeps no neighbour table at level %d",
                 cc.name, cc.level_out);
   if (cc.fin && !(g.ntw == 1 && ds && g.S == 1)) return fail(SPS_ERR_INVALID, "final fusion needs NT = 1, S = 1");
+  c->last_kernel = cs.K == 81 ? (cc.level_out >= 2 ? "k_conv<3x3x3x3, levels 2-4>" : "k_conv<3x3x3x3, levels 0-1>") : "k_conv<2x2x2x1 stride 2>";
   if (cc.fin) {
     hipLaunchKernelGGL((k_conv<1, SPS_G1DS, SPS_W1, true, true, 1>), grid, dim3(256), 0, st, a);
     return SPS_OK;
@@ -865,8 +871,11 @@ void prof_mark(sps_ctx *c, const char *name, hipStream_t st) {
     if (hipEventCreate(&e) != hipSuccess) return;
     c->prof_ev.push_back(e);
     c->prof_names.emplace_back();
+    c->prof_kernels.emplace_back();
   }
   c->prof_names[c->prof_n] = name;
+  c->prof_kernels[c->prof_n] = c->last_kernel;
+  c->last_kernel = "";
   (void)hipEventRecord(c->prof_ev[c->prof_n], st);
   ++c->prof_n;
 }
@@ -1271,6 +1280,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     hipLaunchKernelGGL(k_voxel_feat_mean, dim3((unsigned)grid_for(n, 256, 2048)), dim3(256), 0, st, c->counts, c->vacc,
                        c->vcnt, c->vfeat);
   }
+  c->last_kernel = "k_points_to_blocks+k_rank_points+k_rank_blocks_rows";
   prof_mark(c, "voxelize", st);
   // ---- level links + block adjacency, one launch
   // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
@@ -1289,6 +1299,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
       hipLaunchKernelGGL(k_link_adj, dim3(4 * gb + co[NLV]), dim3(256), 0, st, pa, gb, co[1], co[2], co[3], co[4], co[5]);
     }
   }
+  c->last_kernel = "k_link_adj";
   prof_mark(c, "pyramid", st);
   // ---- kernel maps, one launch
   MapsArgs ma{};
@@ -1323,6 +1334,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   }
   c->diag_have_state = true;
   }  // !skip_front
+  c->last_kernel = "k_maps";
   prof_mark(c, "maps", st);
   if (fo.front_only) {
     HIP_TRY(hipGetLastError());
@@ -1372,6 +1384,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     const ConvSpec &fs = s.convs[s.find_conv("final")];
     hipLaunchKernelGGL(k_slice_head, dim3((unsigned)gs), dim3(256), 0, st, c->b8o, 8, L0.inv, (int)n,
                        c->blob + fs.w_off, c->blob + s.bias_off, s.out_channels, fo.act, scores, fo.ldo, c->counts + 15);
+    c->last_kernel = "k_slice_head";
     prof_mark(c, "slice_head", st);
     if (!skip_front) hipLaunchKernelGGL(k_bhash_cleanup, dim3(gbc * NLV), dim3(256), 0, st, pa, gbc);
   } else if (skip_front || (no_merge & 8)) {
@@ -1390,6 +1403,7 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
     hipLaunchKernelGGL(k_tail, dim3((unsigned)(gst + gbc * NLV)), dim3(256), 0, st, c->logits, L0.inv, (int)n, scores, gst,
                        pa, gbc, mt);
   }
+  c->last_kernel = fo.head ? "k_bhash_cleanup" : "k_tail";
   prof_mark(c, "tail", st);
   HIP_TRY(hipGetLastError());
   c->tables_dirty = false;
@@ -1413,6 +1427,13 @@ int sps_profile_enable(sps_ctx *c, int on) {
 }
 
 int sps_profile_count(sps_ctx *c) { return c && c->prof_n > 0 ? (int)c->prof_n - 1 : 0; }
+
+int sps_profile_kernel(sps_ctx *c, int idx, char *name, int name_cap) {
+  if (!c || !name || name_cap < 1 || idx < 0 || idx + 1 >= (int)c->prof_n) return fail(SPS_ERR_INVALID, "bad stage index");
+  std::strncpy(name, c->prof_kernels[idx + 1].c_str(), (size_t)name_cap - 1);
+  name[name_cap - 1] = 0;
+  return SPS_OK;
+}
 
 int sps_profile_read(sps_ctx *c, int idx, char *name, int name_cap, float *ms) {
   if (!c || !ms || idx < 0 || idx + 1 >= (int)c->prof_n) return fail(SPS_ERR_INVALID, "bad stage index");
