@@ -1,6 +1,7 @@
 /* oracle/sps_oracle.c -- plain C restatement of the SPS per-scan hot path, structured like
  * MinkowskiEngine's CPU backend (coordinate hash map -> kernel maps -> per-kernel-offset
- * gather / small GEMM / scatter-add, offsets ascending).
+ * gather / small GEMM / scatter-add, offsets ascending) -- executed tile by tile of output rows so that it scales with
+ * the host's cores (the sums every output element sees are the per-offset formulation's, in the same order).
  *
  * TEST INFRASTRUCTURE ONLY: the checker for tests/ and the timed "cpu_baseline" (kind "port") of
  * bench.py.  Nothing under sps_amd/ links, loads or calls it.
@@ -98,10 +99,23 @@ static inline int32_t floordiv(int32_t a, int32_t b) { /* b > 0 */
 }
 
 /* ------------------------------------------------------------------ kernel maps ------- */
+/* A kernel map (App. A.8) = for every offset k the pairs (in_row, out_row) with in_coord == out_coord + offset_k.
+ * Stored as a table -- nbr[k * n_out + u] = the input row paired with output row u through offset k, or -1 -- which holds
+ * exactly ME's per-offset in / out lists (list k = the rows u with nbr[k * n_out + u] >= 0, u ascending) and lets every
+ * stage run in parallel over TILES OF OUTPUT ROWS instead of one fork-join per offset (round 4: the per-offset loops
+ * stopped scaling at 16 threads).  inv_k / inv_row (stride maps only): for every INPUT row its one (offset, output row)
+ * -- the transposed convolution's view of the same map (App. A.10). */
+#define TILE 64
 typedef struct {
   int K;
-  int32_t **in, **out; /* per offset */
-  int32_t *len;
+  int32_t n_out;
+  int32_t *nbr;     /* [K][n_out] */
+  int32_t *inv_k;   /* [n_in] or NULL */
+  int32_t *inv_row; /* [n_in] or NULL */
+  /* ME's per-offset pair lists, cut at the tiles of TILE output rows: the pairs of (tile t, offset k) are
+   * pin / pout [ pstart[t * (K + 1) + k] .. pstart[t * (K + 1) + k + 1] ), output rows ascending */
+  int64_t *pstart;
+  int32_t *pin, *pout;
 } kmap_t;
 
 /* offsets (App. A.6/A.7): x fastest, t slowest; odd k centred, even k {0..k-1}; spatial * ts */
@@ -119,75 +133,124 @@ static int make_offsets(const int ks[4], int ts, int32_t (*off)[4]) {
   return K;
 }
 
-/* pairs (in_row, out_row) with in_coord == out_coord + offset_k (App. A.8) */
-static void kmap_build(kmap_t *km, const cmap_t *in, const cmap_t *out, const int ks[4], int ts) {
+static void kmap_build(kmap_t *km, const cmap_t *in, const cmap_t *out, const int ks[4], int ts, int want_inverse) {
   int32_t off[125][4];
   const int K = make_offsets(ks, ts, off);
   km->K = K;
-  km->in = (int32_t **)calloc((size_t)K, sizeof(int32_t *));
-  km->out = (int32_t **)calloc((size_t)K, sizeof(int32_t *));
-  km->len = (int32_t *)calloc((size_t)K, sizeof(int32_t));
-#pragma omp parallel
-  {
-    int32_t *ti = (int32_t *)malloc(sizeof(int32_t) * (size_t)(out->n + 1));
-    int32_t *to = (int32_t *)malloc(sizeof(int32_t) * (size_t)(out->n + 1));
-#pragma omp for schedule(dynamic, 1)
+  km->n_out = out->n;
+  km->nbr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)out->n * K + 1));
+  km->inv_k = km->inv_row = NULL;
+  if (want_inverse) {
+    km->inv_k = (int32_t *)malloc(sizeof(int32_t) * (size_t)(in->n + 1));
+    km->inv_row = (int32_t *)malloc(sizeof(int32_t) * (size_t)(in->n + 1));
+  }
+  const int32_t ntile0 = (out->n + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int32_t t = 0; t < ntile0; ++t) {
+    const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
     for (int k = 0; k < K; ++k) {
-      int32_t cnt = 0;
-      for (int32_t u = 0; u < out->n; ++u) {
-        int32_t q[5];
+      int32_t *nk = km->nbr + (size_t)k * out->n;
+      for (int32_t u = u0; u < u1; ++u) {
         const int32_t *c = out->coords + 5 * (size_t)u;
-        q[0] = c[0];
-        for (int a = 0; a < 4; ++a) q[1 + a] = c[1 + a] + off[k][a];
+        const int32_t q[5] = {c[0], c[1] + off[k][0], c[2] + off[k][1], c[3] + off[k][2], c[4] + off[k][3]};
         const int32_t r = cmap_find(in, q);
-        if (r >= 0) {
-          ti[cnt] = r;
-          to[cnt] = u;
-          ++cnt;
+        nk[u] = r;
+        if (want_inverse && r >= 0) { /* a fine voxel has exactly one parent and one offset: written once */
+          km->inv_k[r] = k;
+          km->inv_row[r] = u;
         }
       }
-      km->len[k] = cnt;
-      km->in[k] = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt + 1));
-      km->out[k] = (int32_t *)malloc(sizeof(int32_t) * (size_t)(cnt + 1));
-      memcpy(km->in[k], ti, sizeof(int32_t) * (size_t)cnt);
-      memcpy(km->out[k], to, sizeof(int32_t) * (size_t)cnt);
     }
-    free(ti);
-    free(to);
   }
+  /* compact the table into the per-(tile, offset) pair lists: count, prefix over the tiles, fill */
+  const int32_t ntile = (out->n + TILE - 1) / TILE;
+  km->pstart = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ntile * (K + 1) + 1));
+  int64_t *ttot = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ntile + 1));
+#pragma omp parallel for schedule(static)
+  for (int32_t t = 0; t < ntile; ++t) {
+    const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
+    int64_t run = 0;
+    for (int k = 0; k < K; ++k) {
+      km->pstart[(size_t)t * (K + 1) + k] = run;
+      const int32_t *nk = km->nbr + (size_t)k * out->n;
+      for (int32_t u = u0; u < u1; ++u) run += nk[u] >= 0;
+    }
+    km->pstart[(size_t)t * (K + 1) + K] = run;
+    ttot[t] = run;
+  }
+  int64_t total = 0;
+  for (int32_t t = 0; t < ntile; ++t) {
+    const int64_t c = ttot[t];
+    ttot[t] = total;
+    total += c;
+  }
+  km->pin = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total + 1));
+  km->pout = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total + 1));
+#pragma omp parallel for schedule(static)
+  for (int32_t t = 0; t < ntile; ++t) {
+    const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
+    int64_t w = ttot[t];
+    for (int k = 0; k <= K; ++k) km->pstart[(size_t)t * (K + 1) + k] += ttot[t];
+    for (int k = 0; k < K; ++k) {
+      const int32_t *nk = km->nbr + (size_t)k * out->n;
+      for (int32_t u = u0; u < u1; ++u)
+        if (nk[u] >= 0) {
+          km->pin[w] = nk[u];
+          km->pout[w] = u;
+          ++w;
+        }
+    }
+  }
+  free(ttot);
 }
 static void kmap_free(kmap_t *km) {
-  if (!km->in) return;
-  for (int k = 0; k < km->K; ++k) {
-    free(km->in[k]);
-    free(km->out[k]);
-  }
-  free(km->in);
-  free(km->out);
-  free(km->len);
-  km->in = NULL;
+  free(km->nbr);
+  free(km->inv_k);
+  free(km->inv_row);
+  free(km->pstart);
+  free(km->pin);
+  free(km->pout);
+  km->nbr = km->inv_k = km->inv_row = NULL;
+  km->pstart = NULL;
+  km->pin = km->pout = NULL;
 }
 
 /* ------------------------------------------------------------------ layers ------------ */
-/* out[n_out,cout] = sum_k scatter( gather(in, map_k) @ W[k] ), k ascending; transpose swaps the
- * roles of the map's in/out lists (App. A.10).  in has row stride ldi. */
+static inline void row_gemm_acc(const float *a, int cin, const float *Wk, int cout, float *o) {
+  for (int ci = 0; ci < cin; ++ci) {
+    const float av = a[ci];
+    const float *w = Wk + (size_t)ci * cout;
+    for (int co = 0; co < cout; ++co) o[co] += av * w[co];
+  }
+}
+
+/* out[n_out,cout] = sum_k gather(in, map_k) @ W[k], offsets ASCENDING per output row -- the order in which ME's
+ * per-offset gather / GEMM / scatter-add passes reach that row, so every output element sees the same sequence of f32
+ * additions as in the per-offset formulation.  Parallel over tiles of 64 output rows; inside a tile offset after offset
+ * (the offset's weight block stays in L1 for the tile's pairs: kmap_t.pin / pout).  transpose: the roles of the map's in / out swap
+ * (App. A.10): every row of the FINE level receives its one term.  in has row stride ldi. */
 static void sparse_conv(const float *in, int ldi, int cin, float *out, int32_t n_out, int cout, const kmap_t *km,
                         const float *W, int transpose) {
-  memset(out, 0, sizeof(float) * (size_t)n_out * (size_t)cout);
-  for (int k = 0; k < km->K; ++k) {
-    const int32_t *src = transpose ? km->out[k] : km->in[k];
-    const int32_t *dst = transpose ? km->in[k] : km->out[k];
-    const float *Wk = W + (size_t)k * cin * cout;
-    const int32_t P = km->len[k];
+  if (transpose) {
 #pragma omp parallel for schedule(static)
-    for (int32_t p = 0; p < P; ++p) { /* each dst row appears at most once per k */
-      const float *a = in + (size_t)src[p] * ldi;
-      float *o = out + (size_t)dst[p] * cout;
-      for (int ci = 0; ci < cin; ++ci) {
-        const float av = a[ci];
-        const float *w = Wk + (size_t)ci * cout;
-        for (int co = 0; co < cout; ++co) o[co] += av * w[co];
-      }
+    for (int32_t v = 0; v < n_out; ++v) {
+      float *o = out + (size_t)v * cout;
+      for (int co = 0; co < cout; ++co) o[co] = 0.f;
+      row_gemm_acc(in + (size_t)km->inv_row[v] * ldi, cin, W + (size_t)km->inv_k[v] * cin * cout, cout, o);
+    }
+    return;
+  }
+  const int K = km->K;
+  const int32_t ntile = (n_out + TILE - 1) / TILE;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int32_t t = 0; t < ntile; ++t) {
+    const int32_t u0 = t * TILE, u1 = u0 + TILE < n_out ? u0 + TILE : n_out;
+    memset(out + (size_t)u0 * cout, 0, sizeof(float) * (size_t)(u1 - u0) * (size_t)cout);
+    const int64_t *ps = km->pstart + (size_t)t * (K + 1);
+    for (int k = 0; k < K; ++k) {
+      const float *Wk = W + (size_t)k * cin * cout;
+      for (int64_t p = ps[k]; p < ps[k + 1]; ++p)
+        row_gemm_acc(in + (size_t)km->pin[p] * ldi, cin, Wk, cout, out + (size_t)km->pout[p] * cout);
     }
   }
 }
@@ -399,9 +462,9 @@ int64_t sps_oracle_forward(const float *coords, int64_t n, int64_t ld, float vs,
   /* ---- kernel maps ---- */
   const int k5s[4] = {5, 5, 5, 1}, k3s[4] = {3, 3, 3, 3}, k2s[4] = {2, 2, 2, 1};
   kmap_t k5, k3[5], kd[4];
-  kmap_build(&k5, &L[0], &L[0], k5s, 1);
-  for (int l = 0; l < 5; ++l) kmap_build(&k3[l], &L[l], &L[l], k3s, 1 << l);
-  for (int l = 0; l < 4; ++l) kmap_build(&kd[l], &L[l], &L[l + 1], k2s, 1 << l); /* in = fine, out = coarse */
+  kmap_build(&k5, &L[0], &L[0], k5s, 1, 0);
+  for (int l = 0; l < 5; ++l) kmap_build(&k3[l], &L[l], &L[l], k3s, 1 << l, 0);
+  for (int l = 0; l < 4; ++l) kmap_build(&kd[l], &L[l], &L[l + 1], k2s, 1 << l, 1); /* in = fine, out = coarse */
   const double t2 = now_s();
   /* ---- network (minkunet.py:161-219) ---- */
   const int32_t V0 = L[0].n;
