@@ -327,8 +327,15 @@ def main():
                 acc[name] = acc.get(name, 0.0) + ms / reps
         kernel_of = dict(zip([n for n, _ in ctx.profile_read()], ctx.profile_kernels()))
         ctx.profile_enable(False)
+        def stage_work(name):
+            """algorithmic work of a stage; a fused launch "a+b" (a transposed convolution in its producer's epilogue) carries both"""
+            parts = [work["per_layer"].get(p) for p in name.split("+")]
+            if any(p is None for p in parts):
+                return None
+            return {k: sum(p[k] for p in parts) for k in ("bytes", "flops")}
+
         for name in order:
-            pl = work["per_layer"].get(name)
+            pl = stage_work(name)
             entry = {"stage": name, "ms": round(acc[name], 5)}
             if pl and acc[name] > 0:
                 gbs = pl["bytes"] / (acc[name] * 1e-3) / 1e9
@@ -348,7 +355,7 @@ def main():
                 cl["bytes"] += pl["bytes"]
                 cl["flops"] += pl["flops"]
             stages.append(entry)
-        layer_stages = [s for s in stages if s["stage"] in work["per_layer"]]
+        layer_stages = [s for s in stages if "alg_bytes" in s]
         dom = max(layer_stages, key=lambda s: s["ms"])                      # longest kernel stage
         dom_bytes = max(layer_stages, key=lambda s: s.get("alg_bytes", 0))   # most algorithmic bytes (HBM-shaped)
     # HBM bytes per scan from PMC passes (tools/traffic_pmc.py): only if they were taken with THIS build of the kernels

@@ -51,6 +51,17 @@ struct ConvArgs {
   int *ticket;
   uint32_t slab_bytes;
   int ws_target, ws_smax;
+  // transposed convolution fused into this layer's epilogue (k_conv<..., UNT > 0>, k_conv_px<..., UP>): the tile of output
+  // rows this workgroup has just finished IS the parent tile k_upconv would load (minkunet.py:107-146: convtrXpYs2 follows
+  // blockX.conv2).  Weights / folded BN of the transposed layer, the stride map's child table (down[k][parent row]) with its
+  // per-tile octant masks, and the fine level's output buffer (the `up` columns of the concat buffer)
+  const float *up_Wu, *up_scale, *up_shift;
+  const int *up_down;
+  const uint32_t *up_tmask;
+  float *up_out;
+  int64_t up_ldn;
+  int up_ldo, up_cout, up_rows;
+  uint32_t up_wu_bytes;
 };
 
 // Output-stationary sparse convolution on f32 MFMA.
@@ -87,14 +98,22 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_wave_trace[4 * 32768];
 #endif
 
-template <int NTW, int G, int MINW, bool DS, bool FIN, int S>
-__global__ __launch_bounds__(S == 8 ? 512 : 256, MINW) void k_conv(ConvArgs a) {
+// CG > 1: the CG column groups of a tile share ONE workgroup (256 * CG threads) instead of CG workgroups -- so that the
+// workgroup ends up with complete output rows.  UNT > 0: the transposed convolution that follows the layer (UNT = its
+// column tiles) runs in the epilogue: the finished tile (BN, residual, ReLU applied) is parked in LDS and the workgroup's
+// waves multiply it with the eight octant kernels and scatter the children through the stride map, as k_upconv does from
+// global memory -- one launch, one round trip over the parent rows and one workgroup prologue less per layer.
+template <int NTW, int G, int MINW, bool DS, bool FIN, int S, int CG = 1, int UNT = 0>
+__global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvArgs a) {
 #if defined(SPS_WAVE_TRACE)
   const unsigned long long tr_t0 = wall_clock64();
   unsigned long long tr_t1 = 0;
   int tr_tiles = 0, tr_units = 0;
 #endif
-  constexpr int NWV = S == 8 ? 8 : 4;  // waves per workgroup (S = 8: one tile, eight splits, 512 threads)
+  static_assert(CG == 1 || (S == 4 && !FIN), "column groups share a workgroup only in the four-split geometry");
+  static_assert(UNT == 0 || S == 4, "the fused transposed convolution needs one tile per workgroup");
+  constexpr int NW1 = S == 8 ? 8 : 4;  // waves per column group (S = 8: one tile, eight splits, 512 threads)
+  constexpr int NWV = NW1 * CG;        // waves per workgroup
   __shared__ unsigned char klist[NWV][128];
   __shared__ uint32_t aoff_s[NWV][KCHUNK * 16];
   __shared__ uint32_t woff_s[NWV][KCHUNK];
@@ -103,15 +122,21 @@ __global__ __launch_bounds__(S == 8 ? 512 : 256, MINW) void k_conv(ConvArgs a) {
   const int ntiles = (count + 15) >> 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 15, q = lane >> 4;
+  const int cg = CG == 1 ? 0 : wave / NW1;             // this wave's column group inside the workgroup
+  const int w1 = CG == 1 ? wave : wave - cg * NW1;     // ... and its index inside the group
   // grid = (column groups, tile groups): the column groups of one tile are dispatched back to back, so every
   // workgroup that has work starts before the idle tail of the grid (tile groups past the device-side count)
-  const int nt0 = blockIdx.x * NTW;
+  const int nt0 = ((int)blockIdx.x * CG + cg) * NTW;
   // split-K inside the workgroup: its four waves are (4 / S) tiles x S splits of the tile's unit list; the
   // partial sums meet in LDS (fixed order -> deterministic), so there is no slab in HBM and no second launch
-  constexpr int tpw = NWV / S;                         // S = 1, 2, 4 or 8; tiles per workgroup
-  const int tl = S == 1 ? wave : wave / S;
-  const int split = S == 1 ? 0 : wave - tl * S;
-  __shared__ float red_s[S > 1 ? (NWV - tpw) * NTW * 4 * 64 : 1];
+  constexpr int tpw = NW1 / S;                         // S = 1, 2, 4 or 8; tiles per workgroup
+  const int tl = S == 1 ? w1 : w1 / S;
+  const int split = S == 1 ? 0 : w1 - tl * S;
+  __shared__ float red_s[S > 1 ? CG * (NW1 - tpw) * NTW * 4 * 64 : 1];
+  // fused transposed convolution: the finished tile, complete rows (row stride + 4 floats: the 16-byte reads of the 16 rows
+  // of a lane group fall on different banks)
+  constexpr int XLD = CG * NTW * 16 + 4;
+  __shared__ __attribute__((aligned(16))) float x_s[UNT > 0 ? 16 * XLD : 4];
   unsigned char *kl = klist[wave];
   uint32_t *ao = aoff_s[wave];
   uint32_t *wo = woff_s[wave];
@@ -329,22 +354,24 @@ __global__ __launch_bounds__(S == 8 ? 512 : 256, MINW) void k_conv(ConvArgs a) {
     if constexpr (S > 1) {
       __syncthreads();  // the previous group's reader is done with red_s
       if (split != 0) {
-        float *rd = red_s + (tl * (S - 1) + split - 1) * (NTW * 4 * 64) + lane;
+        float *rd = red_s + ((cg * tpw + tl) * (S - 1) + split - 1) * (NTW * 4 * 64) + lane;
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
           for (int i = 0; i < 4; ++i) rd[(nt * 4 + i) * 64] = acc[nt][i];
       }
       __syncthreads();
-      if (split != 0) continue;
-      for (int sp = 1; sp < S; ++sp) {  // s ascending, as the former reduce kernel summed the slabs
-        const float *rd = red_s + (tl * (S - 1) + sp - 1) * (NTW * 4 * 64) + lane;
+      if (UNT == 0 && split != 0) continue;
+      if (split == 0) {
+        for (int sp = 1; sp < S; ++sp) {  // s ascending, as the former reduce kernel summed the slabs
+          const float *rd = red_s + ((cg * tpw + tl) * (S - 1) + sp - 1) * (NTW * 4 * 64) + lane;
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt)
+          for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-          for (int i = 0; i < 4; ++i) acc[nt][i] += rd[(nt * 4 + i) * 64];
+            for (int i = 0; i < 4; ++i) acc[nt][i] += rd[(nt * 4 + i) * 64];
+        }
       }
-      if (!active) continue;
+      if (UNT == 0 && !active) continue;
     }
     // ---- epilogue.  C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
     if (NTW == 1 && FIN) {
@@ -367,19 +394,76 @@ __global__ __launch_bounds__(S == 8 ? 512 : 256, MINW) void k_conv(ConvArgs a) {
       }
       continue;
     }
+    if (UNT == 0 || (split == 0 && active)) {
 #pragma unroll
-    for (int nt = 0; nt < NTW; ++nt) {
-      const int col = (nt0 + nt) * 16 + r;
-      if (col >= a.cout) continue;
-      const float sc = esc[nt], sh = esh[nt];
+      for (int nt = 0; nt < NTW; ++nt) {
+        const int col = (nt0 + nt) * 16 + r;
+        if (col >= a.cout) continue;
+        const float sc = esc[nt], sh = esh[nt];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ro = row0 + q * 4 + i;
-        if (ro >= count) continue;
-        float y = acc[nt][i] * sc + sh;
-        if (a.res) y += a.res[(size_t)ro * a.ldr + col];
-        if (a.relu) y = fmaxf(y, 0.f);
-        a.out[(size_t)ro * a.ldo + col] = y;
+        for (int i = 0; i < 4; ++i) {
+          const int ro = row0 + q * 4 + i;
+          if (ro >= count) continue;
+          float y = acc[nt][i] * sc + sh;
+          if (a.res) y += a.res[(size_t)ro * a.ldr + col];
+          if (a.relu) y = fmaxf(y, 0.f);
+          a.out[(size_t)ro * a.ldo + col] = y;
+          if (UNT > 0) x_s[(q * 4 + i) * XLD + col] = y;
+        }
+      }
+    }
+    if constexpr (UNT > 0) {
+      // ---- fused transposed convolution (k_upconv on the tile just parked in x_s).  Wave w of the NWV takes the octants
+      // w * 8 / NWV ...: D[16 parents x 16 UNT] = X . Wtr[k], folded BN + ReLU, one scattered row store per child.
+      // (rows >= count of a last tile were never written: their children are -1)
+      __syncthreads();
+      if (active) {  // workgroup-uniform (one tile per workgroup)
+        constexpr int CINU = CG * NTW * 16;   // channels of the parked rows = C_in of the transposed convolution
+        constexpr int UPKU = CINU / 4;
+        constexpr int OPW = 8 / NWV;          // octants per wave (2 or 1)
+        const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void *)a.up_Wu, 0, (int)a.up_wu_bytes, 0x00020000);
+        const uint32_t omask = a.up_tmask[(size_t)tile * 4] & 0xFFu;
+#pragma unroll
+        for (int kk = 0; kk < OPW; ++kk) {
+          const int k = wave * OPW + kk;
+          if (!((omask >> k) & 1u)) continue;  // no row of this tile has a child at octant k (wave-uniform)
+          int child[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ro = row0 + q * 4 + i;
+            child[i] = ro < count ? a.up_down[(size_t)k * a.up_ldn + ro] : -1;
+            if (child[i] >= a.up_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+          }
+          floatx4 uacc[UNT];
+#pragma unroll
+          for (int nt = 0; nt < UNT; ++nt) uacc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ig = 0; ig < UPKU / 4; ++ig) {
+            const floatx4 xa = *reinterpret_cast<const floatx4 *>(x_s + r * XLD + (4 * ig + q) * 4);
+            const uint32_t ob = ((uint32_t)(k * UPKU + 4 * ig + q) * (uint32_t)UNT) * 256u + (uint32_t)r * 16u;
+            u32x4 vb[UNT];
+#pragma unroll
+            for (int nt = 0; nt < UNT; ++nt) vb[nt] = __builtin_amdgcn_raw_buffer_load_b128(rsU, ob + nt * 256u, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < UNT; ++nt) {
+              uacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, __uint_as_float(vb[nt].x), uacc[nt], 0, 0, 0);
+              uacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, __uint_as_float(vb[nt].y), uacc[nt], 0, 0, 0);
+              uacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, __uint_as_float(vb[nt].z), uacc[nt], 0, 0, 0);
+              uacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, __uint_as_float(vb[nt].w), uacc[nt], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int nt = 0; nt < UNT; ++nt) {
+            const int col = nt * 16 + r;
+            if (col >= a.up_cout) continue;
+            const float sc = a.up_scale[col], sh = a.up_shift[col];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (child[i] < 0) continue;
+              a.up_out[(size_t)child[i] * a.up_ldo + col] = fmaxf(uacc[nt][i] * sc + sh, 0.f);  // bntr + ReLU (minkunet.py:188-190)
+            }
+          }
+        }
       }
     }
   }
@@ -427,8 +511,11 @@ struct PxOperands {  // gathered rows + weight fragments of a group of G chunks
   u32x2 xa[G], xb[G];
   uint32_t e[G];
 };
-template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW>
+// UP: the transposed convolution that follows the layer (C_out = 16 -> <= 16 channels, block7.conv2 -> convtr7p2s2) runs in
+// the epilogue on the supertile's 64 finished rows, which stay in the first accumulator (see the epilogue).
+template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW, bool UP = false>
 __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
+  static_assert(!UP || (!C8 && !FIN && NW == 4), "fused transposed convolution: 16-channel rows, four waves");
   constexpr int AST = C8 ? 12 : 20;    // floats per accumulator row: 16-byte aligned, strides 48 / 80 B spread the banks
   constexpr int ACCN = 64 * AST + 16;  // + one dummy row (PAD slots)
   constexpr bool W128 = CIN >= 16, W64 = CIN != 16;  // 16-byte part (channels 0..15), 8-byte part (8 channels)
@@ -630,11 +717,51 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
           if (ro < count) a.out[(size_t)ro * a.ldo + col] = y;
           if (FIN) fsum += y * a.fin_w[col];
         }
+        if (UP) acc_s[0][rr * AST + col] = y;  // (this thread alone read the slot: the finished row stays here for the octants)
       }
       if (FIN) {
 #pragma unroll
         for (int o = 1; o < TPR; o <<= 1) fsum += __shfl_xor(fsum, o, 64);
         if ((threadIdx.x % TPR) == 0 && ro < count) a.fin_out[ro] = fsum + a.fin_b;
+      }
+    }
+    if constexpr (UP) {
+      // ---- fused transposed convolution (k_upconv on the 64 rows parked in acc_s[0]): wave w takes the octants 2 w, 2 w + 1
+      // of all four 16-row tiles -- one weight fragment per octant, four MFMAs per tile, folded BN + ReLU, one scattered row
+      // store per child (minkunet.py:140-146, :212-214)
+      __syncthreads();
+      const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void *)a.up_Wu, 0, (int)a.up_wu_bytes, 0x00020000);
+      const float usc = n < a.up_cout ? a.up_scale[n] : 0.f, ush = n < a.up_cout ? a.up_shift[n] : 0.f;
+      uint32_t om[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) om[t] = row0 + 16 * t < count ? a.up_tmask[(size_t)(st * 4 + t) * 4] & 0xFFu : 0u;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int k = 2 * wave + kk;
+        if (!(((om[0] | om[1] | om[2] | om[3]) >> k) & 1u)) continue;  // wave-uniform
+        const u32x4 vb = __builtin_amdgcn_raw_buffer_load_b128(rsU, (uint32_t)(k * 4 + q) * 256u + (uint32_t)n * 16u, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          if (!((om[t] >> k) & 1u)) continue;  // no row of this tile has a child at octant k (wave-uniform)
+          int child[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int ro = row0 + 16 * t + q * 4 + i;
+            child[i] = ro < count ? a.up_down[(size_t)k * a.up_ldn + ro] : -1;
+            if (child[i] >= a.up_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+          }
+          const floatx4 xa = *reinterpret_cast<const floatx4 *>(acc_s[0] + (16 * t + n) * AST + 4 * q);
+          floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.x, __uint_as_float(vb.x), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.y, __uint_as_float(vb.y), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.z, __uint_as_float(vb.z), d, 0, 0, 0);
+          d = __builtin_amdgcn_mfma_f32_16x16x4f32(xa.w, __uint_as_float(vb.w), d, 0, 0, 0);
+          if (n < a.up_cout) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+              if (child[i] >= 0) a.up_out[(size_t)child[i] * a.up_ldo + n] = fmaxf(d[i] * usc + ush, 0.f);
+          }
+        }
       }
     }
     PX_STAMP(6);

@@ -568,7 +568,24 @@ struct ConvCall {
   const float *in2 = nullptr;  // fused downsample input (block input x)
   int ldi2 = 0;
   bool fin = false;            // fuse the `final` 1x1 conv into the epilogue
+  const char *up = nullptr;    // transposed convolution fused into the epilogue (its output: up_out / up_ldo)
+  float *up_out = nullptr;
+  int up_ldo = 0;
 };
+
+// Transposed convolutions run in the epilogue of the layer that produces their input (minkunet.py:107-146: convtrXpYs2
+// follows blockX.conv2).  SPS_FUSE_UP: bit 0 = convtr4 into block4.conv2, 1 = convtr5 into block5.conv2, 2 = convtr6 into
+// block6.conv2, 3 = convtr7 into block7.conv2; -DSPS_FUSE_UP=0 keeps the four k_upconv launches (A/B builds).
+// Measured (tools/ab_bench.sh, one box, three alternating runs each; resident-input scans/s | serial kernel time per scan):
+//   0: 3 994 | 512 us    8: 3 996 | 510    12: 3 985 | 502.5    15: 3 943 | 501
+// The two 64-channel producers (bits 0, 1) need both column groups of a tile in ONE 8-wave workgroup to own complete rows:
+// half as many, twice as heavy workgroups on 256 CUs (317 tiles at level 3: 61 CUs carry two) -- their launches shrink by
+// 1.5 us where k_upconv took 11 and the pipelined rate falls 1.3 %.  Default 12: block6.conv2 (one column group anyway:
+// 29.2 -> 24.0 us for the pair) and block7.conv2 (pair-exact: the 64 finished rows sit in LDS; 31.4 -> 29.3 us).
+#ifndef SPS_FUSE_UP
+#define SPS_FUSE_UP 12
+#endif
+constexpr int FUSE_UP = SPS_FUSE_UP;
 
 // Launch geometry per output level (config-2 sizes: 108k / 43k / 15k / 5k / 1.7k rows).  The fine
 // levels have thousands of 16-row tiles; the coarse ones need split-N (one 16-column tile per wave)
@@ -610,13 +627,27 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   return g;
 }
 
-template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW>
+template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW, bool UP = false>
 void launch_px(dim3 grid, hipStream_t st, const ConvArgs &a) {
-  hipLaunchKernelGGL((k_conv_px<NW, CIN, C8, DS, FIN, MINW>), grid, dim3(NW * 64), 0, st, a);
+  hipLaunchKernelGGL((k_conv_px<NW, CIN, C8, DS, FIN, MINW, UP>), grid, dim3(NW * 64), 0, st, a);
 }
 
 // k_conv instantiation for a launch geometry (column tiles per wave x splits) -- shared by inference and training
 int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t st, unsigned lds_pad = 0) {
+  if (a.up_out) {  // fused transposed convolution: the three wide decoder-side producers (block4 / 5 / 6 .conv2)
+    const int cgs = a.NT / g.ntw;                       // column groups of a tile, all in one workgroup
+    const int unt = (a.up_cout + 15) / 16;
+    if (!(g.ntw == 2 && g.S == 4 && ds)) return fail(SPS_ERR_INVALID, "fused transposed convolution: geometry ntw = %d, S = %d", g.ntw, g.S);
+    if (cgs == 1 && unt == 1)
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 1, 1>), grid, dim3(256), lds_pad, st, a);
+    else if (cgs == 2 && unt == 2)
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 2, 2>), grid, dim3(512), lds_pad, st, a);
+    else if (cgs == 2 && unt == 4)
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 2, 4>), grid, dim3(512), lds_pad, st, a);
+    else
+      return fail(SPS_ERR_INVALID, "fused transposed convolution: no instantiation for %d column groups, %d output tiles", cgs, unt);
+    return SPS_OK;
+  }
 #define SPS_LAUNCH(NTW_, G_, W_, S_)                                                              \
   do {                                                                                            \
     if (ds)                                                                                       \
@@ -684,7 +715,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   static const int max_wg = [] { const char *e = diag_env("SPS_CONV_MAX_WG"); return e ? atoi(e) : 0; }();
   if (max_wg > 0 && gx * (a.NT / g.ntw) * g.S > max_wg) gx = std::max<int64_t>(16, max_wg / ((a.NT / g.ntw) * g.S));
   // a workgroup holds 4 / S tiles x S splits: S times as many workgroups for the same tiles
-  const dim3 grid((unsigned)(a.NT / g.ntw), (unsigned)(gx * g.S), 1u);  // x = column group (fastest), y = tile group
+  dim3 grid((unsigned)(a.NT / g.ntw), (unsigned)(gx * g.S), 1u);  // x = column group (fastest), y = tile group
   a.in2 = cc.in2;
   a.ldi2 = cc.ldi2;
   a.upk2 = cs.ds_cin / 4;
@@ -707,6 +738,25 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.tile_order = (TILE_ORDER != 0 && cs.K == 81 && cc.level_out >= TILE_ORDER_FIRST_LEVEL) ? c->lv[cc.level_out].tile_order : nullptr;
   // workgroups are dealt to the CUs in block-index order (column group fastest): positions p and p + 256 / column groups share a CU
   a.order_ways = TILE_ORDER == 2 ? TILE_ORDER_WAYS / std::max(1, a.NT / g.ntw) : 0;
+  if (cc.up) {
+    // the transposed convolution that consumes this layer's output runs in its epilogue: all column groups of a tile in one
+    // workgroup (complete rows), the stride map's child table of THIS (the coarse) level, the fine level's buffer
+    const ConvSpec &us = s.convs[s.find_conv(cc.up)];
+    if (us.cin != cs.cout || cc.level_out < 1) return fail(SPS_ERR_INVALID, "%s cannot be fused into %s", cc.up, cc.name);
+    a.up_Wu = c->wu + us.wu_off;
+    a.up_scale = c->ss + us.ss_off;
+    a.up_shift = c->ss + us.ss_off + us.cout;
+    a.up_down = c->lv[cc.level_out].down;
+    a.up_tmask = c->lv[cc.level_out].tmdown;
+    a.up_ldn = c->capl[cc.level_out];
+    a.up_out = cc.up_out;
+    a.up_ldo = cc.up_ldo;
+    a.up_cout = us.cout;
+    a.up_rows = (int)c->capl[cc.level_out - 1];
+    a.up_wu_bytes = (uint32_t)(us.wu_numel() * 4);
+    grid.x = 1;
+    a.order_ways = TILE_ORDER == 2 ? TILE_ORDER_WAYS : 0;
+  }
   {
     static const char *trace_layer = diag_env("SPS_TRACE_LAYER");  // diagnostic builds (-DSPS_WAVE_TRACE) only
     a.trace_on = trace_layer && std::strcmp(trace_layer, cc.name) == 0;
@@ -787,7 +837,14 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       case 810: SPS_PX_LAUNCH(8, true, false, false); break;    // block1.conv1 / conv2
       case 811: SPS_PX_LAUNCH(8, true, true, false); break;     // block8.conv2 (heads: `final` not fused)
       case 812: SPS_PX_LAUNCH(8, true, true, true); break;      // block8.conv2 + `final`
-      case 1601: SPS_PX_LAUNCH(16, false, true, false); break;  // block2.conv2, block7.conv2
+      case 1601:                                                // block7.conv2 (+ convtr7p2s2 in its epilogue)
+        if (cc.up) {
+          if (cc.level_out != 1 || a.up_cout > 16) return fail(SPS_ERR_INVALID, "%s cannot be fused into %s", cc.up, cc.name);
+          launch_px<SPS_PX1, 16, false, true, false, SPS_PX1_W, true>(gridp, st, a);
+        } else {
+          SPS_PX_LAUNCH(16, false, true, false);
+        }
+        break;
       case 1610: SPS_PX_LAUNCH(16, true, false, false); break;  // block8.conv1
       case 2400: SPS_PX_LAUNCH(24, false, false, false); break; // block7.conv1
       default: return fail(SPS_ERR_INVALID, "no k_conv_px instantiation for %s", cc.name);
@@ -1357,25 +1414,44 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
       {"block3.0.conv2", c->b3t, 32, c->cat5 + 64, 96, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->x3, 16},
       {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, Map{lv[4].down, lv[4].tmdown}, 4, nullptr, 0, 1},
       {"block4.0.conv1", c->x4, 32, c->b4t, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1},
-      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1, c->x4, 32},
+      {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1, c->x4, 32, false,
+       (FUSE_UP & 1) ? "convtr4p16s2" : nullptr, c->cat5, 96},
       {"convtr4p16s2", c->b4o, 64, c->cat5, 96, Map{lv[4].down, lv[4].tmdown}, 3, nullptr, 0, 1},
       {"block5.0.conv1", c->cat5, 96, c->b5t, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
-      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->cat5, 96},
+      {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->cat5, 96, false,
+       (FUSE_UP & 2) ? "convtr5p8s2" : nullptr, c->cat6, 48},
       {"convtr5p8s2", c->b5o, 64, c->cat6, 48, Map{lv[3].down, lv[3].tmdown}, 2, nullptr, 0, 1},
       {"block6.0.conv1", c->cat6, 48, c->b6t, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
-      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1, c->cat6, 48},
+      {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1, c->cat6, 48, false,
+       (FUSE_UP & 4) ? "convtr6p4s2" : nullptr, c->cat7, 24},
       {"convtr6p4s2", c->b6o, 32, c->cat7, 24, Map{lv[2].down, lv[2].tmdown}, 1, nullptr, 0, 1},
       {"block7.0.conv1", c->cat7, 24, c->b7t, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1},
-      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1, c->cat7, 24},
+      {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1, c->cat7, 24, false,
+       (FUSE_UP & 8) ? "convtr7p2s2" : nullptr, c->cat8, 16},
       {"convtr7p2s2", c->b7o, 16, c->cat8, 16, Map{lv[1].down, lv[1].tmdown}, 0, nullptr, 0, 1},
       {"block8.0.conv1", c->cat8, 16, c->b8t, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1},
       {"block8.0.conv2", c->b8t, 8, c->b8o, 8, Map{lv[0].nbr3, lv[0].tm3}, 0, nullptr, 0, 1, c->cat8, 16, fuse_final},
   };
+  const char *fused_up = nullptr;  // the transposed convolution the previous launch ran in its epilogue
+  static const char *const fused_stage[][2] = {{"block4.0.conv2", "block4.0.conv2+convtr4p16s2"},
+                                               {"block5.0.conv2", "block5.0.conv2+convtr5p8s2"},
+                                               {"block6.0.conv2", "block6.0.conv2+convtr6p4s2"},
+                                               {"block7.0.conv2", "block7.0.conv2+convtr7p2s2"}};
   for (const ConvCall &cc : calls) {
     if (skip_convs) break;
+    if (fused_up && std::strcmp(cc.name, fused_up) == 0) {  // already done
+      fused_up = nullptr;
+      continue;
+    }
     int rc = run_conv(c, cc, st);
     if (rc != SPS_OK) return rc;
-    prof_mark(c, cc.name, st);
+    const char *stage = cc.name;
+    if (cc.up) {
+      fused_up = cc.up;
+      for (const auto &fs : fused_stage)
+        if (std::strcmp(cc.name, fs[0]) == 0) stage = fs[1];
+    }
+    prof_mark(c, stage, st);
   }
   c->cur_vfeat = nullptr;
   const int gs = (int)((n + 255) / 256), gbc = grid_for(cap >> 2, 256, 256);
