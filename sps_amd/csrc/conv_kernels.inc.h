@@ -517,7 +517,10 @@ template <int NW, int CIN, bool C8, bool DS, bool FIN, int MINW, bool UP = false
 __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   static_assert(!UP || (!C8 && !FIN && NW == 4), "fused transposed convolution: 16-channel rows, four waves");
   constexpr int AST = C8 ? 12 : 20;    // floats per accumulator row: 16-byte aligned, strides 48 / 80 B spread the banks
-  constexpr int ACCN = 64 * AST + 16;  // + one dummy row (PAD slots)
+  // + dummy slots (PAD entries; C_out <= 8: also the lane groups 2, 3 that hold the zero-padded channels 8..15).  C8: one
+  // 16-byte slot PER LANE, so that every lane runs the same branch-free read-add-write (round 4: the exec-masked update cost
+  // two mask regions and a branch per chunk, and the kernel is bound by instruction issue)
+  constexpr int ACCN = 64 * AST + (C8 ? 256 : 16);
   constexpr bool W128 = CIN >= 16, W64 = CIN != 16;  // 16-byte part (channels 0..15), 8-byte part (8 channels)
   constexpr uint32_t OFF64 = CIN == 24 ? 64u : 0u;   // byte offset of the 8-byte part inside a row
   constexpr uint32_t U64 = CIN == 24 ? 4u : 0u;      // first weight unit of the 8-byte part
@@ -529,7 +532,8 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   const bool tr_on = a.trace_on;
 #endif
   PX_STAMP(0);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // scalar: the per-chunk "is there a chunk" tests stay on the SALU
   const int n = lane & 15, q = lane >> 4;
   // the first supertile's entry does not depend on the row count: fetch it alongside (one round trip less).  With a balanced
   // order (a.px_order: {supertile, chunks per slice} by position) the position's supertile comes with its chunk counts.
@@ -629,7 +633,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       const uint32_t ew = (uint32_t)__shfl((int)ev, 16 * j + n, 64);
       r.e[0] = on ? ew : PX_PAD;
       const uint32_t wk = on ? (uint32_t)__builtin_amdgcn_readlane((int)kv, j) * kwbytes : 0x80000000u;
-      const uint32_t ioff = r.e[0] == PX_PAD ? OOR : (r.e[0] >> 6) * ldi4;
+      const uint32_t ioff = r.e[0] == PX_PAD ? OOR : __umul24(r.e[0] >> 6, ldi4);  // (rows < 2^23, row bytes < 2^24)
       if (W128) {
         if (QUAD) {
           // quad-contiguous gather: lane l fetches unit l & 3 of pair l >> 2, so the four lanes of a quad read ONE 64-byte
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
           // ds_bpermute.  Measured: block7.conv1 (C_in = 24) 25.0 -> 22.2 us, block8.conv1 (C_in = 16) 31.8 -> 33.6 us --
           // only the C_in = 24 instantiation uses it
           const uint32_t eq = (uint32_t)__shfl((int)ev, 16 * j + (lane >> 2), 64);
-          const uint32_t ioq = (!on || eq == PX_PAD) ? OOR : (eq >> 6) * ldi4;
+          const uint32_t ioq = (!on || eq == PX_PAD) ? OOR : __umul24(eq >> 6, ldi4);
           r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioq + (uint32_t)(lane & 3) * 16u, 0, 0);
         } else {
           r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
@@ -650,10 +654,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       }
     };
     auto compute = [&](const PxOperands<1> &r) {
-      const int orow = r.e[0] == PX_PAD ? 64 : (int)(r.e[0] & 63u);
-      floatx4 *ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
-      floatx4 cur = floatx4{0.f, 0.f, 0.f, 0.f};
-      if (rmw) cur = *ap;
+      floatx4 *ap;
+      if (C8) {  // every lane updates SOME slot: its pair's row (lane groups 0, 1 of a real pair) or its own dummy slot
+        const bool real = r.e[0] != PX_PAD && q < 2;
+        ap = reinterpret_cast<floatx4 *>(acc + (real ? (int)(r.e[0] & 63u) * AST + 4 * q : 64 * AST + 4 * lane));
+      } else {
+        const int orow = r.e[0] == PX_PAD ? 64 : (int)(r.e[0] & 63u);
+        ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
+      }
+      floatx4 cur = *ap;
       floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
       if (W128) {
         uint32_t ax = r.va[0].x, ay = r.va[0].y, az = r.va[0].z, aw = r.va[0].w;
@@ -671,7 +680,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[0].x), __uint_as_float(r.xa[0].x), d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(r.xb[0].y), __uint_as_float(r.xa[0].y), d, 0, 0, 0);
       }
-      if (rmw) *ap = cur + d;
+      *ap = cur + d;
     };
     if (nbw > 0) {
       uint32_t ev0, kv0, ev1, kv1;
