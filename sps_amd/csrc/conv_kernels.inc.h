@@ -120,7 +120,7 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
   if (a.abort_flag && *a.abort_flag) return;
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: wave-uniform tests stay on the SALU)
   const int r = lane & 15, q = lane >> 4;
   const int cg = CG == 1 ? 0 : wave / NW1;             // this wave's column group inside the workgroup
   const int w1 = CG == 1 ? wave : wave - cg * NW1;     // ... and its index inside the group
@@ -1125,7 +1125,7 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
   if (a.abort_flag && *a.abort_flag) return;
   const int count = *a.n_out;
   const int ntiles = (count + 15) >> 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: wave-uniform tests stay on the SALU)
   const int r = lane & 15, q = lane >> 4;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
@@ -1225,7 +1225,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
   __syncthreads();
   const int n = *n_out;
   const int ntiles = (n + 15) >> 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: wave-uniform tests stay on the SALU)
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
   for (int tile = bid * 4 + wave; tile < ntiles; tile += g0 * 4) {
@@ -1360,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
   __syncthreads();
   const int n = *n_out;
   const int ntiles = (n + 15) >> 4;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: wave-uniform tests stay on the SALU)
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
   float *va = val_s[wave][r];
