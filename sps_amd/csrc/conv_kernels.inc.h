@@ -274,29 +274,41 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
 #endif
         u32x4 va[G];
         u32x4 vb[G][NTW];
+        // the byte offsets of all G groups come out of LDS first (unconditional reads at clamped indices, one wait), then
+        // the 3 G loads are issued back to back.  (Written as `valid ? ao[..] : OOR` the compiler put every LDS read into an
+        // exec-masked branch with its own wait: two LDS round trips per group in front of its loads.)
+        uint32_t aov[G], wov[G], c4v[G];
+        bool val[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-          const bool valid = jb + 4 * g + q < ju1;
+          val[g] = jb + 4 * g + q < ju1;
           const int kkc = min(kk, KCHUNK - 1);
-#if defined(SPS_ABLATE_A)
-          const uint32_t oa = OOR;
-          (void)ao;
-#else
-          const uint32_t oa = valid ? ao[kkc * 16 + r] + (uint32_t)c4 * 16u : OOR;
-#endif
-#if defined(SPS_ABLATE_B)
-          const uint32_t ob = OOR;
-#else
-          const uint32_t ob = valid ? wo[kkc] + (uint32_t)c4 * wunit + wlane : OOR;
-#endif
-          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+          aov[g] = ao[kkc * 16 + r];
+          wov[g] = wo[kkc];
+          c4v[g] = (uint32_t)c4;
           c4 += cstep;
           kk += kstep;
           const int wrap = c4 >= upk ? 1 : 0;   // branch-free carry of the (k, c4) counter
           c4 -= wrap ? upk : 0;
           kk += wrap;
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(aov[g]), "+v"(wov[g]));  // (keeps the reads out of the selects below)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+#if defined(SPS_ABLATE_A)
+          const uint32_t oa = OOR;
+#else
+          const uint32_t oa = val[g] ? aov[g] + c4v[g] * 16u : OOR;
+#endif
+#if defined(SPS_ABLATE_B)
+          const uint32_t ob = OOR;
+#else
+          const uint32_t ob = val[g] ? wov[g] + __umul24(c4v[g], wunit) + wlane : OOR;
+#endif
+          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+#pragma unroll
+          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
         }
 #if defined(SPS_ABLATE_MFMA)
 #pragma unroll
