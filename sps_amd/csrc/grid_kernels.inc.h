@@ -24,10 +24,21 @@ struct BHash {
   int *rank;                 // block rank (first-occurrence order)
   uint32_t *occ;             // 1 bit per slot: "slot in use" -- a cache-resident filter in front of keys[]
   uint32_t hmask;
+  uint32_t hshift;           // 32 - log2(slots): a slot = the TOP bits of the 32-bit hash
 };
 
+// Block hash: LINEAR in the block coordinates (a lattice hash, large odd multipliers, top bits) -- the hash of the block at
+// offset (dx, dy, dz, dt) is this block's hash plus a constant, so the adjacency build (81 probes per block, k_link_adj)
+// pays one addition per probe instead of two 64-bit multiplies (round 4; 15.5 -> see DESIGN 3.0).  The 10 bits above the
+// coordinates are (batch, time index).
+constexpr uint32_t BH_X = 0x9E3779B1u, BH_Y = 0x85EBCA77u, BH_Z = 0xC2B2AE3Du, BH_T = 0x27D4EB2Fu;
+__device__ inline uint32_t bhash32(uint64_t key) {
+  return (uint32_t)(key & 0x3FFFF) * BH_X + (uint32_t)((key >> 18) & 0x3FFFF) * BH_Y + (uint32_t)((key >> 36) & 0x3FFFF) * BH_Z +
+         (uint32_t)(key >> 54) * BH_T;
+}
+
 __device__ inline int bhash_insert(const BHash &h, uint64_t key) {
-  uint32_t s = hash64(key) & h.hmask;
+  uint32_t s = bhash32(key) >> h.hshift;
   while (true) {
     unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long *>(&h.keys[s]),
                                         (unsigned long long)KEY_EMPTY, (unsigned long long)key);
@@ -46,7 +57,7 @@ __device__ inline int bhash_find_from(const BHash &h, uint64_t key, uint32_t s) 
   }
 }
 __device__ inline int bhash_find(const BHash &h, uint64_t key) {
-  uint32_t s = hash64(key) & h.hmask;
+  uint32_t s = bhash32(key) >> h.hshift;
   while (true) {
     if (!((h.occ[s >> 5] >> (s & 31)) & 1u)) return -1;
     if (h.keys[s] == key) return (int)s;
@@ -501,7 +512,7 @@ __device__ inline void link_levels(const PyramidArgs &a, int l, int bx, int nbx)
 // kernel-map build: 81 per BLOCK instead of 81..125 per voxel.
 // One launch with link_levels (both only need the block ranks of all levels): workgroups [0, 4 * gb) link.
 // A scan + submap batch holds two time indices (util.py:20-21): a third of the probes is answered by the TOCC bits.
-constexpr int LINK_ILP = 4;  // adjacency entries a thread resolves at once
+constexpr int LINK_PER = 3;  // adjacency entries a thread resolves: the three dx neighbours of one (dy, dz, dt)
 #if defined(SPS_FE_TRACE)
 __device__ unsigned long long g_link_trace[2 * 16384];
 struct LinkStamp {
@@ -520,60 +531,68 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
   }
   // workgroup -> (level, chunk): chunk offsets 0, c1, c2, c3, c4, c5 (expected sizes, grid-stride beyond), COARSEST level
   // first: its few workgroups have the longest dependent chains and used to start last.
-  // The launch is bound by residency x latency, not by work: a workgroup holds its slot for the ~2.3 us of the dependent
-  // chain key -> occupancy word -> slot key -> rank whatever it does (8 700 one-probe workgroups: 12 us until the last one
-  // STARTED), so a thread walks LINK_ILP entries at once, phase by phase: the loads of a phase are independent.
+  // A thread = one block and one (dy, dz, dt): it decodes the key and hashes it ONCE, the three dx neighbours are the key
+  // plus a constant and the hash plus a constant; the probes run phase by phase (occupancy word -> slot key -> rank:
+  // the loads of a phase are independent) and the three results are stored side by side.  (Nine per thread -- all (dx, dy)
+  // of a (dz, dt) -- measured 3 us SLOWER than round 3's kernel: ~80 VGPRs, too few waves to hide the three round trips.)  (Round 3: one entry per thread,
+  // ~150 instructions per probe -- two 64-bit multiplies of the hash, divisions by 81 / 27 / 9 / 3 -- bound the launch.)
   const int bx = (int)blockIdx.x - 4 * gb;
   const int idx = bx < c1 ? 0 : bx < c2 ? 1 : bx < c3 ? 2 : bx < c4 ? 3 : 4;
   const int level = NLV - 1 - idx;
   const int lo = idx == 0 ? 0 : idx == 1 ? c1 : idx == 2 ? c2 : idx == 3 ? c3 : c4;
   const int hi = idx == 0 ? c1 : idx == 1 ? c2 : idx == 2 ? c3 : idx == 3 ? c4 : c5;
-  const int total = a.counts[8 + level] * 81;  // < 2^31: blocks <= points <= 2^23
-  const int lim = 1 << (16 - level);  // block coordinates of this level live in [0, lim)
+  const int total = a.counts[8 + level] * 27;  // (block, dy, dz, dt) tuples
+  const int lim = 1 << (16 - level);          // block coordinates of this level live in [0, lim)
   const BHash h = a.h[level];
   const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];  // a time index no block has needs no probe
   const uint64_t *__restrict__ bkey = a.bkey[level];
   int *__restrict__ badj = a.badj[level];
-  for (int i0 = (bx - lo) * (256 * LINK_ILP) + (int)threadIdx.x; i0 < total; i0 += (hi - lo) * (256 * LINK_ILP)) {
-    uint64_t nk[LINK_ILP];
-    uint32_t sl[LINK_ILP];
-    int res[LINK_ILP];
-    bool probe[LINK_ILP];
+  for (int i = (bx - lo) * 256 + (int)threadIdx.x; i < total; i += (hi - lo) * 256) {
+    const int r = i / 27, g = i - r * 27;
+    const int dy = g % 3 - 1, dz = (g / 3) % 3 - 1, dt = g / 9 - 1;
+    const uint64_t key = bkey[r];
+    const int kx = (int)(key & 0x3FFFF), ky = (int)((key >> 18) & 0x3FFFF) + dy, kz = (int)((key >> 36) & 0x3FFFF) + dz,
+              tt = (int)((key >> 54) & 0x1F) + dt;
+    const bool gok = ky >= 0 && ky < lim && kz >= 0 && kz < lim && tt >= 0 && tt < 32 && ((tocc >> tt) & 1u);
+    // key / hash of the (0, dy, dz, dt) neighbour; the dx ones add constants (the fields cannot carry where gok and the
+    // x test below hold)
+    const uint64_t gkey = key + ((uint64_t)(int64_t)dy << 18) + ((uint64_t)(int64_t)dz << 36) + ((uint64_t)(int64_t)dt << 54);
+    const uint32_t ghash = bhash32(key) + (uint32_t)dy * BH_Y + (uint32_t)dz * BH_Z + (uint32_t)dt * BH_T;
+    uint64_t nk[LINK_PER];
+    uint32_t sl[LINK_PER];
+    int res[LINK_PER];
+    bool probe[LINK_PER];
 #pragma unroll
-    for (int u = 0; u < LINK_ILP; ++u) {
-      const int i = i0 + u * 256;
-      const int r = min(i, total - 1) / 81, ad = min(i, total - 1) - r * 81;
-      const uint64_t key = bkey[r];
-      const int bxx = (int)(key & 0x3FFFF) + (ad % 3 - 1), by = (int)((key >> 18) & 0x3FFFF) + ((ad / 3) % 3 - 1),
-                bz = (int)((key >> 36) & 0x3FFFF) + ((ad / 9) % 3 - 1), tt = (int)((key >> 54) & 0x1F) + (ad / 27 - 1);
-      res[u] = ad == 40 ? r : -1;
-      probe[u] = i < total && ad != 40 && bxx >= 0 && bxx < lim && by >= 0 && by < lim && bz >= 0 && bz < lim && tt >= 0 && tt < 32 &&
-                 ((tocc >> tt) & 1u);
-      nk[u] = bkey_pack((uint32_t)(key >> 59), (uint32_t)tt, (uint32_t)bxx, (uint32_t)by, (uint32_t)bz);
-      sl[u] = hash64(nk[u]) & h.hmask;
+    for (int j = 0; j < LINK_PER; ++j) {
+      const int dx = j - 1;  // compile-time
+      const bool self = dx == 0 && g == 13;
+      res[j] = self ? r : -1;
+      probe[j] = gok && !self && kx + dx >= 0 && kx + dx < lim;
+      nk[j] = gkey + (uint64_t)(int64_t)dx;
+      sl[j] = (ghash + (uint32_t)dx * BH_X) >> h.hshift;
     }
-    uint32_t ow[LINK_ILP];
+    uint32_t ow[LINK_PER];
 #pragma unroll
-    for (int u = 0; u < LINK_ILP; ++u) ow[u] = probe[u] ? h.occ[sl[u] >> 5] : 0u;
-    uint64_t k1[LINK_ILP];
+    for (int j = 0; j < LINK_PER; ++j) ow[j] = probe[j] ? h.occ[sl[j] >> 5] : 0u;
+    uint64_t k1[LINK_PER];
 #pragma unroll
-    for (int u = 0; u < LINK_ILP; ++u) {
-      probe[u] = probe[u] && ((ow[u] >> (sl[u] & 31)) & 1u);  // a free first slot: the block does not exist
-      k1[u] = probe[u] ? h.keys[sl[u]] : KEY_EMPTY;
+    for (int j = 0; j < LINK_PER; ++j) {
+      probe[j] = probe[j] && ((ow[j] >> (sl[j] & 31)) & 1u);  // a free first slot: the block does not exist
+      k1[j] = probe[j] ? h.keys[sl[j]] : KEY_EMPTY;
     }
 #pragma unroll
-    for (int u = 0; u < LINK_ILP; ++u) {
-      if (!probe[u]) continue;
-      if (k1[u] == nk[u]) {
-        res[u] = h.rank[sl[u]];
+    for (int j = 0; j < LINK_PER; ++j) {
+      if (!probe[j]) continue;
+      if (k1[j] == nk[j]) {
+        res[j] = h.rank[sl[j]];
       } else {  // the first slot holds another block: walk on (rare)
-        const int s2 = bhash_find_from(h, nk[u], (sl[u] + 1) & h.hmask);
-        if (s2 >= 0) res[u] = h.rank[s2];
+        const int s2 = bhash_find_from(h, nk[j], (sl[j] + 1) & h.hmask);
+        if (s2 >= 0) res[j] = h.rank[s2];
       }
     }
+    int *__restrict__ o = badj + (size_t)r * 81 + g * 3;
 #pragma unroll
-    for (int u = 0; u < LINK_ILP; ++u)
-      if (i0 + u * 256 < total) badj[i0 + u * 256] = res[u];
+    for (int j = 0; j < LINK_PER; ++j) o[j] = res[j];
   }
 }
 

@@ -375,6 +375,12 @@ int reserve(sps_ctx *c, int64_t n) {
       ALLOC(L.h.rank, int, hc);
       L.h.occ = occ + hoff / 32;
       L.h.hmask = (uint32_t)(hc - 1);
+      {
+        int lg = 0;
+        while ((int64_t(1) << lg) < hc) ++lg;
+        if ((int64_t(1) << lg) != hc) return fail(SPS_ERR_INVALID, "internal: block hash capacity %lld is not a power of two", (long long)hc);
+        L.h.hshift = (uint32_t)(32 - lg);
+      }
       hoff += hc;
       ALLOC(L.bslot, int, blocks);
       ALLOC(L.bkey, uint64_t, blocks);
@@ -1343,8 +1349,8 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
   // expected blocks <= rows / 4; 81 probes per block, ~1 probe per thread (grid-stride beyond that)
   {
     int co[NLV + 1] = {0};
-    // chunk i = level NLV - 1 - i (coarsest first); a workgroup resolves 256 * LINK_ILP entries per step
-    for (int i = 0; i < NLV; ++i) co[i + 1] = co[i] + grid_for(((cap >> 3) >> (2 * (NLV - 1 - i))) * 81, 256 * LINK_ILP, 2048);
+    // chunk i = level NLV - 1 - i (coarsest first); a thread resolves the three dx entries of one (block, dy, dz, dt)
+    for (int i = 0; i < NLV; ++i) co[i + 1] = co[i] + grid_for(((cap >> 3) >> (2 * (NLV - 1 - i))) * 27, 256, 2048);
 #if defined(SPS_FE_TRACE)
     g_link_geom[0] = gb;
     for (int l = 0; l <= NLV; ++l) g_link_geom[1 + l] = co[l];
