@@ -267,69 +267,90 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
       int kk = (int)(((float)jl + 0.5f) * a.inv_upk);
       int c4 = jl - kk * upk;
       kk -= kc;
-#if defined(SPS_ABLATE_LOOP)
-      for (int jb = ju0; jb < ju0; jb += 4 * G) {
-#else
-      for (int jb = ju0; jb < ju1; jb += 4 * G) {
-#endif
-        u32x4 va[G];
-        u32x4 vb[G][NTW];
-        // the byte offsets of all G groups come out of LDS first (unconditional reads at clamped indices, one wait), then
-        // the 3 G loads are issued back to back.  (Written as `valid ? ao[..] : OOR` the compiler put every LDS read into an
-        // exec-masked branch with its own wait: two LDS round trips per group in front of its loads.)
-        uint32_t aov[G], wov[G], c4v[G];
-        bool val[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-          val[g] = jb + 4 * g + q < ju1;
-          const int kkc = min(kk, KCHUNK - 1);
-          aov[g] = ao[kkc * 16 + r];
-          wov[g] = wo[kkc];
-          c4v[g] = (uint32_t)c4;
-          c4 += cstep;
-          kk += kstep;
-          const int wrap = c4 >= upk ? 1 : 0;   // branch-free carry of the (k, c4) counter
-          c4 -= wrap ? upk : 0;
-          kk += wrap;
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(aov[g]), "+v"(wov[g]));  // (keeps the reads out of the selects below)
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
+      // ---- unit loop as a ROTATING pipeline of G operand sets (round 4).  Rounds 1-3 issued the loads of G groups, waited,
+      // and ran their 4 G NTW MFMAs before the next round's loads went out: every round the wave drained to zero loads in
+      // flight, and a diagnostic build without loads AND MFMAs showed the loop's wall time to be far above either alone
+      // (tools/ab_bench.sh: no loads +4 %, no MFMAs +7 %, neither +44 % pipelined) -- dependent round trips, not a pipe.
+      // Now group g's registers are refilled with the group's units of the NEXT round right behind its MFMAs, so 2 .. 3
+      // groups' loads are always in flight while one group multiplies, with no more registers than before.  The byte
+      // offsets of a refill come out of LDS before the MFMAs that free the registers (their latency hides behind them).
+      u32x4 va[G];
+      u32x4 vb[G][NTW];
+      uint32_t p_aov, p_wov, p_c4;  // prepared (LDS reads done) for the next issue
+      bool p_val;
+      auto prep = [&](int jg) {     // jg = first unit of the group to prepare; advances this lane's (k, c4) counter
+        p_val = jg + q < ju1;
+        const int kkc = min(kk, KCHUNK - 1);
+        p_aov = ao[kkc * 16 + r];
+        p_wov = wo[kkc];
+        p_c4 = (uint32_t)c4;
+        c4 += cstep;
+        kk += kstep;
+        const int wrap = c4 >= upk ? 1 : 0;   // branch-free carry of the (k, c4) counter
+        c4 -= wrap ? upk : 0;
+        kk += wrap;
+      };
+      auto issue = [&](int g) {
+        asm volatile("" : "+v"(p_aov), "+v"(p_wov));  // (keeps the unconditional LDS reads out of the selects below)
 #if defined(SPS_ABLATE_A)
-          const uint32_t oa = OOR;
+        const uint32_t oa = OOR;
 #else
-          const uint32_t oa = val[g] ? aov[g] + c4v[g] * 16u : OOR;
+        const uint32_t oa = p_val ? p_aov + p_c4 * 16u : OOR;
 #endif
 #if defined(SPS_ABLATE_B)
-          const uint32_t ob = OOR;
+        const uint32_t ob = OOR;
 #else
-          const uint32_t ob = val[g] ? wov[g] + __umul24(c4v[g], wunit) + wlane : OOR;
+        const uint32_t ob = p_val ? p_wov + __umul24(p_c4, wunit) + wlane : OOR;
 #endif
-          va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+        va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) {
+#if defined(SPS_ABLATE_HALF_B)
+          // DIAGNOSTIC (wrong results): the weight fragment of every second column tile is an out-of-range load (zeros, no
+          // cache access) -- the weight traffic a 32 x 32 x 2 MFMA tiling would have (one B fragment per 32 rows instead
+          // of one per 16) at unchanged MFMA work: an UPPER bound of what that tiling can gain
+          vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, (nt & 1) ? OOR : ob + nt * 256u, 0, 0);
+#else
+          vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+#endif
         }
+      };
+      auto mfma = [&](int g) {
 #if defined(SPS_ABLATE_MFMA)
+        asm volatile("" ::"v"(va[g].x), "v"(va[g].y), "v"(va[g].z), "v"(va[g].w));
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
-          asm volatile("" ::"v"(va[g].x), "v"(va[g].y), "v"(va[g].z), "v"(va[g].w));
-#pragma unroll
-          for (int nt = 0; nt < NTW; ++nt)
-            asm volatile("" ::"v"(vb[g][nt].x), "v"(vb[g][nt].y), "v"(vb[g][nt].z), "v"(vb[g][nt].w));
-        }
+        for (int nt = 0; nt < NTW; ++nt)
+          asm volatile("" ::"v"(vb[g][nt].x), "v"(vb[g][nt].y), "v"(vb[g][nt].z), "v"(vb[g][nt].w));
 #else
 #pragma unroll
-        for (int g = 0; g < G; ++g) {
+        for (int nt = 0; nt < NTW; ++nt) {
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb[g][nt].x), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb[g][nt].y), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb[g][nt].z), acc[nt], 0, 0, 0);
+          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
+        }
+#endif
+      };
+#if defined(SPS_ABLATE_LOOP)
+      if (false) {
+#else
+      if (ju0 < ju1) {
+#endif
+        // branch-free on purpose: a group past the end of the list loads out-of-range (zeros, no cache access) and its MFMAs
+        // add zeros -- with per-group tests the compiler's wait-count insertion drained the pipeline at every merge point
 #pragma unroll
-          for (int nt = 0; nt < NTW; ++nt) {
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].x), __uint_as_float(vb[g][nt].x), acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].y), __uint_as_float(vb[g][nt].y), acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].z), __uint_as_float(vb[g][nt].z), acc[nt], 0, 0, 0);
-            acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[g].w), __uint_as_float(vb[g][nt].w), acc[nt], 0, 0, 0);
+        for (int g = 0; g < G; ++g) {  // fill the pipeline
+          prep(ju0 + 4 * g);
+          issue(g);
+        }
+        for (int jb = ju0; jb < ju1; jb += 4 * G) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            prep(jb + 4 * G + 4 * g);  // this group's units of the next round (none in the last round: an out-of-range refill)
+            mfma(g);
+            issue(g);
           }
         }
-#endif
       }
     }
     // ---- fused residual branch: r = downsample(x) = x[row] @ Wds (identity map), last split only

@@ -45,6 +45,7 @@
 #if !defined(SPS_DIAG)  // the ablation / trace blocks exist in -DSPS_DIAG builds only
 #undef SPS_ABLATE_A
 #undef SPS_ABLATE_B
+#undef SPS_ABLATE_HALF_B
 #undef SPS_ABLATE_MFMA
 #undef SPS_ABLATE_LOOP
 #undef SPS_ABLATE_STAGE
