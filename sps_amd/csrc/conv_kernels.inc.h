@@ -103,7 +103,8 @@ __device__ unsigned long long g_wave_trace[4 * 32768];
 // column tiles) runs in the epilogue: the finished tile (BN, residual, ReLU applied) is parked in LDS and the workgroup's
 // waves multiply it with the eight octant kernels and scatter the children through the stride map, as k_upconv does from
 // global memory -- one launch, one round trip over the parent rows and one workgroup prologue less per layer.
-template <int NTW, int G, int MINW, bool DS, bool FIN, int S, int CG = 1, int UNT = 0>
+// U4: C_in is a multiple of 16 -- the unit loop runs on scalar (offset, unit) counters (see the loop).
+template <int NTW, int G, int MINW, bool DS, bool FIN, int S, int CG = 1, int UNT = 0, bool U4 = false>
 __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvArgs a) {
 #if defined(SPS_WAVE_TRACE)
   const unsigned long long tr_t0 = wall_clock64();
@@ -331,11 +332,65 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
         }
 #endif
       };
-#if defined(SPS_ABLATE_LOOP)
-      if (false) {
+      // C_in a multiple of 16 (every wide layer): the four units of a group belong to ONE offset, so the group's place in
+      // the list is wave-uniform -- (offset, first unit) advance on the SCALAR unit, a lane adds its constant part.  (The
+      // per-lane (k, c4) counters of the general loop cost ~20 vector instructions per group of 8 MFMAs; a diagnostic build
+      // with loads AND MFMAs compiled out still spent 44 of the 246 us of a pipelined scan in these loops.)
+      constexpr bool up4 = U4;  // (the host picks the instantiation: upk % 4 == 0)
+      int ks = 0, cs = 0;            // fast path: offset (relative to the chunk) and first unit inside it of the next group
+      if (up4) {
+        const int k0 = (int)(((float)ju0 + 0.5f) * a.inv_upk);
+        ks = __builtin_amdgcn_readfirstlane(k0 - kc), cs = __builtin_amdgcn_readfirstlane(ju0 - k0 * upk);  // (scalar registers)
+      }
+      const uint32_t qa = (uint32_t)q * 16u, qw = (uint32_t)q * wunit + wlane;
+      uint32_t p_sa = 0u, p_sw = 0u;  // fast path: the group's scalar byte offsets (input row, weights)
+      auto prep4 = [&](int jg) {
+        p_val = jg < ju1;            // wave-uniform
+        const int kkc = min(ks, KCHUNK - 1);
+        p_aov = ao[kkc * 16 + r];
+        p_wov = wo[kkc];
+        p_sa = (uint32_t)cs * 16u, p_sw = (uint32_t)cs * wunit;
+        cs += 4;
+        if (cs >= upk) cs = 0, ++ks;
+      };
+      auto issue4 = [&](int g) {
+        asm volatile("" : "+v"(p_aov), "+v"(p_wov));
+#if defined(SPS_ABLATE_A)
+        const uint32_t oa = OOR;
 #else
-      if (ju0 < ju1) {
+        const uint32_t oa = p_val ? p_aov + p_sa + qa : OOR;
 #endif
+#if defined(SPS_ABLATE_B)
+        const uint32_t ob = OOR;
+#else
+        const uint32_t ob = p_val ? p_wov + p_sw + qw : OOR;
+#endif
+        va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+      };
+#if defined(SPS_ABLATE_LOOP)
+      const bool run_loop = false;
+#else
+      const bool run_loop = ju0 < ju1;
+#endif
+      if constexpr (up4) {
+       if (run_loop) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) {  // fill the pipeline
+          prep4(ju0 + 4 * g);
+          issue4(g);
+        }
+        for (int jb = ju0; jb < ju1; jb += 4 * G) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) {
+            prep4(jb + 4 * G + 4 * g);
+            mfma(g);
+            issue4(g);
+          }
+        }
+       }
+      } else if (run_loop) {
         // branch-free on purpose: a group past the end of the list loads out-of-range (zeros, no cache access) and its MFMAs
         // add zeros -- with per-group tests the compiler's wait-count insertion drained the pipeline at every merge point
 #pragma unroll

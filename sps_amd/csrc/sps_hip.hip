@@ -646,11 +646,11 @@ int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t
     const int unt = (a.up_cout + 15) / 16;
     if (!(g.ntw == 2 && g.S == 4 && ds)) return fail(SPS_ERR_INVALID, "fused transposed convolution: geometry ntw = %d, S = %d", g.ntw, g.S);
     if (cgs == 1 && unt == 1)
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 1, 1>), grid, dim3(256), lds_pad, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 1, 1, true>), grid, dim3(256), lds_pad, st, a);
     else if (cgs == 2 && unt == 2)
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 2, 2>), grid, dim3(512), lds_pad, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 2, 2, true>), grid, dim3(512), lds_pad, st, a);
     else if (cgs == 2 && unt == 4)
-      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 2, 4>), grid, dim3(512), lds_pad, st, a);
+      hipLaunchKernelGGL((k_conv<2, SPS_G2, 4, true, false, 4, 2, 4, true>), grid, dim3(512), lds_pad, st, a);
     else
       return fail(SPS_ERR_INVALID, "fused transposed convolution: no instantiation for %d column groups, %d output tiles", cgs, unt);
     return SPS_OK;
@@ -662,6 +662,19 @@ int launch_k_conv(const ConvArgs &a, Geometry g, bool ds, dim3 grid, hipStream_t
     else                                                                                          \
       hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, S_>), grid, dim3(S_ == 8 ? 512 : 256), lds_pad, st, a);    \
   } while (0)
+  // C_in a multiple of 16 (the wide layers of the coarse levels, four splits): the scalar-counter unit loop
+#define SPS_LAUNCH_U4(NTW_, G_, W_)                                                                               \
+  do {                                                                                                            \
+    if (ds)                                                                                                       \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, true, false, 4, 1, 0, true>), grid, dim3(256), lds_pad, st, a);    \
+    else                                                                                                          \
+      hipLaunchKernelGGL((k_conv<NTW_, G_, W_, false, false, 4, 1, 0, true>), grid, dim3(256), lds_pad, st, a);   \
+  } while (0)
+  if (g.S == 4 && (a.upk & 3) == 0 && a.upk > 0 && (!ds || (a.upk2 & 3) == 0)) {
+    if (g.ntw == 1) { SPS_LAUNCH_U4(1, SPS_G1, SPS_WS); return SPS_OK; }
+    if (g.ntw == 2) { SPS_LAUNCH_U4(2, SPS_G2, SPS_W2); return SPS_OK; }
+  }
+#undef SPS_LAUNCH_U4
   const int key = g.ntw * 10 + g.S;
   switch (key) {
     case 11: SPS_LAUNCH(1, SPS_G1, SPS_W1, 1); break;
@@ -784,6 +797,15 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       gto = NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS;
     }
     c->last_kernel = c->cur_vfeat ? "k_conv0_feat" : "k_conv0_fused";
+    {  // DIAGNOSTICS (-DSPS_DIAG): SPS_DIAG_CONV0 = 1: only the hosted order bodies run, 2: only the convolution
+      static const int c0mode = [] { const char *e = diag_env("SPS_DIAG_CONV0"); return e ? atoi(e) : 0; }();
+      if (c0mode == 1) {
+        hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)gto), dim3(256), 0, st, a.n_out, c->lv[0].view(), c->blob + cs.w_off, a.scale,
+                           a.shift, a.in_const, a.out, a.ldo, 1, to, 0);
+        return SPS_OK;
+      }
+      if (c0mode == 2) gto = 0;
+    }
     if (c->cur_vfeat) {
       hipLaunchKernelGGL(k_conv0_feat, dim3((unsigned)(g0 + gto)), dim3(256), 0, st, a.n_out,
                          c->lv[0].view(), c->blob + cs.w_off, a.scale, a.shift, c->cur_vfeat, a.out, a.ldo, to, g0);
@@ -1444,8 +1466,17 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
                                                {"block5.0.conv2", "block5.0.conv2+convtr5p8s2"},
                                                {"block6.0.conv2", "block6.0.conv2+convtr6p4s2"},
                                                {"block7.0.conv2", "block7.0.conv2+convtr7p2s2"}};
+  // DIAGNOSTICS (-DSPS_DIAG builds): SPS_DIAG_SKIP_CLASS bit 0 = skip the 3x3x3x3 layers of levels 2-4, 1 = those of levels
+  // 0-1, 2 = the strided convolutions, 3 = the transposed ones, 4 = conv0 -- what a kernel class costs the PIPELINED rate
+  static const int skip_class = [] { const char *e = diag_env("SPS_DIAG_SKIP_CLASS"); return e ? atoi(e) : 0; }();
   for (const ConvCall &cc : calls) {
     if (skip_convs) break;
+    if (skip_class) {
+      const bool tr = std::strncmp(cc.name, "convtr", 6) == 0, c0 = std::strcmp(cc.name, "conv0p1s1") == 0;
+      const bool blk = std::strncmp(cc.name, "block", 5) == 0, strided = !tr && !c0 && !blk;
+      const int cls = blk ? (cc.level_out >= 2 ? 1 : 2) : strided ? 4 : tr ? 8 : 16;
+      if (skip_class & cls) continue;
+    }
     if (fused_up && std::strcmp(cc.name, fused_up) == 0) {  // already done
       fused_up = nullptr;
       continue;
