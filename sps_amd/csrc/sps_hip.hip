@@ -88,16 +88,16 @@ int fail(int code, const char *fmt, ...) {
 // variant of the unit loop was measured too: no gain -- the fine-level layers are co-limited by the CU's L1
 // throughput for the gathers and by MFMA issue, not by latency.)
 #ifndef SPS_G1
-#define SPS_G1 3
+#define SPS_G1 2  // round 4 (rotating pipeline): two groups per wave in flight: pipelined +0.5 % over three
 #endif
 #ifndef SPS_G1DS
-#define SPS_G1DS 3
+#define SPS_G1DS 2
 #endif
 #ifndef SPS_W1
 #define SPS_W1 7
 #endif
 #ifndef SPS_G2
-#define SPS_G2 3  // round 2: three groups in flight at 5 waves / SIMD: serial 0.504 -> 0.489 ms, pipelined unchanged
+#define SPS_G2 2  // round 4 (rotating pipeline, tools/ab_bench.sh): G = 1 / 2 / 3 / 4 -> 4 112 / 4 134 / 4 081 / 4 019 scans/s pipelined, serial 513 / 488 / 482 / 486 us
 #endif
 #ifndef SPS_W2
 #define SPS_W2 5
