@@ -118,7 +118,7 @@ class ScanEngine:
         ``row + b`` (default: the next free rows).  Returns the scores [N] (device tensor, valid after finish() or a wait
         on stream ``self.last_stream``).
 
-        Measured (tools/streams_h2d_sweep.sh, tools/h2d_probe*.py): with the two buffers and the event
+        Measured (tools/streams_h2d_sweep.sh): with the two buffers and the event
         behind the copy the host-fed loop runs within 3 % of the resident-input loop at 7 streams (3 678 vs 3 776 scans/s);
         one staging buffer and no event: 16 % below it.  A dedicated copy stream is worse either way: a device-side wait
         on the copy's event (hipStreamWaitEvent behind an SDMA copy) costs the HOST 0.3 ms per step, a host-side wait
