@@ -100,22 +100,22 @@ static inline int32_t floordiv(int32_t a, int32_t b) { /* b > 0 */
 
 /* ------------------------------------------------------------------ kernel maps ------- */
 /* A kernel map (App. A.8) = for every offset k the pairs (in_row, out_row) with in_coord == out_coord + offset_k.
- * Stored as a table -- nbr[k * n_out + u] = the input row paired with output row u through offset k, or -1 -- which holds
- * exactly ME's per-offset in / out lists (list k = the rows u with nbr[k * n_out + u] >= 0, u ascending) and lets every
- * stage run in parallel over TILES OF OUTPUT ROWS instead of one fork-join per offset (round 4: the per-offset loops
- * stopped scaling at 16 threads).  inv_k / inv_row (stride maps only): for every INPUT row its one (offset, output row)
+ * Stored as ME's per-offset in / out lists, cut at TILES of output rows, so that every stage runs in parallel over the
+ * tiles instead of one fork-join per offset (round 4: the per-offset loops stopped scaling at 16 threads).  inv_k / inv_row (stride maps only): for every INPUT row its one (offset, output row)
  * -- the transposed convolution's view of the same map (App. A.10). */
 #define TILE 64
 typedef struct {
   int K;
   int32_t n_out;
-  int32_t *nbr;     /* [K][n_out] */
   int32_t *inv_k;   /* [n_in] or NULL */
   int32_t *inv_row; /* [n_in] or NULL */
   /* ME's per-offset pair lists, cut at the tiles of TILE output rows: the pairs of (tile t, offset k) are
-   * pin / pout [ pstart[t * (K + 1) + k] .. pstart[t * (K + 1) + k + 1] ), output rows ascending */
-  int64_t *pstart;
-  int32_t *pin, *pout;
+   * tin[t] / tout[t] [ pstart[t * (K + 1) + k] .. pstart[t * (K + 1) + k + 1] ), output rows ascending.  The lists live in
+   * per-thread arenas (a thread appends the tiles it builds); tin / tout point into them. */
+  int32_t *pstart;
+  int32_t **tin, **tout;
+  int32_t **arena_in, **arena_out;
+  int n_arena;
 } kmap_t;
 
 /* offsets (App. A.6/A.7): x fastest, t slowest; odd k centred, even k {0..k-1}; spatial * ts */
@@ -133,86 +133,87 @@ static int make_offsets(const int ks[4], int ts, int32_t (*off)[4]) {
   return K;
 }
 
+/* One pass: a thread takes tiles of TILE output rows and, offset after offset, probes the input map and appends the pairs
+ * it finds to its own arena. */
 static void kmap_build(kmap_t *km, const cmap_t *in, const cmap_t *out, const int ks[4], int ts, int want_inverse) {
   int32_t off[125][4];
   const int K = make_offsets(ks, ts, off);
+  const int32_t ntile = (out->n + TILE - 1) / TILE;
   km->K = K;
   km->n_out = out->n;
-  km->nbr = (int32_t *)malloc(sizeof(int32_t) * ((size_t)out->n * K + 1));
   km->inv_k = km->inv_row = NULL;
   if (want_inverse) {
     km->inv_k = (int32_t *)malloc(sizeof(int32_t) * (size_t)(in->n + 1));
     km->inv_row = (int32_t *)malloc(sizeof(int32_t) * (size_t)(in->n + 1));
   }
-  const int32_t ntile0 = (out->n + TILE - 1) / TILE;
-#pragma omp parallel for schedule(dynamic, 4)
-  for (int32_t t = 0; t < ntile0; ++t) {
-    const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
-    for (int k = 0; k < K; ++k) {
-      int32_t *nk = km->nbr + (size_t)k * out->n;
-      for (int32_t u = u0; u < u1; ++u) {
-        const int32_t *c = out->coords + 5 * (size_t)u;
-        const int32_t q[5] = {c[0], c[1] + off[k][0], c[2] + off[k][1], c[3] + off[k][2], c[4] + off[k][3]};
-        const int32_t r = cmap_find(in, q);
-        nk[u] = r;
-        if (want_inverse && r >= 0) { /* a fine voxel has exactly one parent and one offset: written once */
-          km->inv_k[r] = k;
-          km->inv_row[r] = u;
+  km->pstart = (int32_t *)malloc(sizeof(int32_t) * ((size_t)ntile * (K + 1) + 1));
+  km->tin = (int32_t **)calloc((size_t)ntile + 1, sizeof(int32_t *));
+  km->tout = (int32_t **)calloc((size_t)ntile + 1, sizeof(int32_t *));
+  int nth = 1;
+#ifdef _OPENMP
+  nth = omp_get_max_threads();
+#endif
+  km->n_arena = nth;
+  km->arena_in = (int32_t **)calloc((size_t)nth, sizeof(int32_t *));
+  km->arena_out = (int32_t **)calloc((size_t)nth, sizeof(int32_t *));
+  /* a tile's lists must not move once tin / tout point at them: every thread reserves the worst case of ITS share up
+   * front -- tiles are dealt in contiguous blocks (static schedule), ceil(ntile / nth) tiles of at most TILE * K pairs,
+   * but the reservation is virtual memory until touched */
+  const int32_t per_thread = (ntile + nth - 1) / nth;
+#pragma omp parallel num_threads(nth)
+  {
+    int me = 0;
+#ifdef _OPENMP
+    me = omp_get_thread_num();
+#endif
+    const size_t cap = (size_t)per_thread * TILE * (size_t)K + 1;
+    int32_t *ai = (int32_t *)malloc(sizeof(int32_t) * cap), *ao = (int32_t *)malloc(sizeof(int32_t) * cap);
+    km->arena_in[me] = ai;
+    km->arena_out[me] = ao;
+    size_t w = 0;
+    const int32_t t0 = me * per_thread, t1 = t0 + per_thread < ntile ? t0 + per_thread : ntile;
+    for (int32_t t = t0; t < t1; ++t) {
+      const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
+      int32_t *ps = km->pstart + (size_t)t * (K + 1);
+      km->tin[t] = ai + w;
+      km->tout[t] = ao + w;
+      const size_t base = w;
+      for (int k = 0; k < K; ++k) {
+        ps[k] = (int32_t)(w - base);
+        for (int32_t u = u0; u < u1; ++u) {
+          const int32_t *c = out->coords + 5 * (size_t)u;
+          const int32_t q[5] = {c[0], c[1] + off[k][0], c[2] + off[k][1], c[3] + off[k][2], c[4] + off[k][3]};
+          const int32_t r = cmap_find(in, q);
+          if (r >= 0) {
+            ai[w] = r;
+            ao[w] = u;
+            ++w;
+            if (want_inverse) { /* a fine voxel has exactly one parent and one offset: written once */
+              km->inv_k[r] = k;
+              km->inv_row[r] = u;
+            }
+          }
         }
       }
+      ps[K] = (int32_t)(w - base);
     }
   }
-  /* compact the table into the per-(tile, offset) pair lists: count, prefix over the tiles, fill */
-  const int32_t ntile = (out->n + TILE - 1) / TILE;
-  km->pstart = (int64_t *)malloc(sizeof(int64_t) * ((size_t)ntile * (K + 1) + 1));
-  int64_t *ttot = (int64_t *)malloc(sizeof(int64_t) * (size_t)(ntile + 1));
-#pragma omp parallel for schedule(static)
-  for (int32_t t = 0; t < ntile; ++t) {
-    const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
-    int64_t run = 0;
-    for (int k = 0; k < K; ++k) {
-      km->pstart[(size_t)t * (K + 1) + k] = run;
-      const int32_t *nk = km->nbr + (size_t)k * out->n;
-      for (int32_t u = u0; u < u1; ++u) run += nk[u] >= 0;
-    }
-    km->pstart[(size_t)t * (K + 1) + K] = run;
-    ttot[t] = run;
-  }
-  int64_t total = 0;
-  for (int32_t t = 0; t < ntile; ++t) {
-    const int64_t c = ttot[t];
-    ttot[t] = total;
-    total += c;
-  }
-  km->pin = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total + 1));
-  km->pout = (int32_t *)malloc(sizeof(int32_t) * (size_t)(total + 1));
-#pragma omp parallel for schedule(static)
-  for (int32_t t = 0; t < ntile; ++t) {
-    const int32_t u0 = t * TILE, u1 = u0 + TILE < out->n ? u0 + TILE : out->n;
-    int64_t w = ttot[t];
-    for (int k = 0; k <= K; ++k) km->pstart[(size_t)t * (K + 1) + k] += ttot[t];
-    for (int k = 0; k < K; ++k) {
-      const int32_t *nk = km->nbr + (size_t)k * out->n;
-      for (int32_t u = u0; u < u1; ++u)
-        if (nk[u] >= 0) {
-          km->pin[w] = nk[u];
-          km->pout[w] = u;
-          ++w;
-        }
-    }
-  }
-  free(ttot);
 }
 static void kmap_free(kmap_t *km) {
-  free(km->nbr);
   free(km->inv_k);
   free(km->inv_row);
   free(km->pstart);
-  free(km->pin);
-  free(km->pout);
-  km->nbr = km->inv_k = km->inv_row = NULL;
-  km->pstart = NULL;
-  km->pin = km->pout = NULL;
+  free(km->tin);
+  free(km->tout);
+  for (int i = 0; i < km->n_arena; ++i) {
+    free(km->arena_in[i]);
+    free(km->arena_out[i]);
+  }
+  free(km->arena_in);
+  free(km->arena_out);
+  km->inv_k = km->inv_row = km->pstart = NULL;
+  km->tin = km->tout = km->arena_in = km->arena_out = NULL;
+  km->n_arena = 0;
 }
 
 /* ------------------------------------------------------------------ layers ------------ */
@@ -227,7 +228,7 @@ static inline void row_gemm_acc(const float *a, int cin, const float *Wk, int co
 /* out[n_out,cout] = sum_k gather(in, map_k) @ W[k], offsets ASCENDING per output row -- the order in which ME's
  * per-offset gather / GEMM / scatter-add passes reach that row, so every output element sees the same sequence of f32
  * additions as in the per-offset formulation.  Parallel over tiles of 64 output rows; inside a tile offset after offset
- * (the offset's weight block stays in L1 for the tile's pairs: kmap_t.pin / pout).  transpose: the roles of the map's in / out swap
+ * (the offset's weight block stays in L1 for the tile's pairs: kmap_t.tin / tout).  transpose: the roles of the map's in / out swap
  * (App. A.10): every row of the FINE level receives its one term.  in has row stride ldi. */
 static void sparse_conv(const float *in, int ldi, int cin, float *out, int32_t n_out, int cout, const kmap_t *km,
                         const float *W, int transpose) {
@@ -246,11 +247,12 @@ static void sparse_conv(const float *in, int ldi, int cin, float *out, int32_t n
   for (int32_t t = 0; t < ntile; ++t) {
     const int32_t u0 = t * TILE, u1 = u0 + TILE < n_out ? u0 + TILE : n_out;
     memset(out + (size_t)u0 * cout, 0, sizeof(float) * (size_t)(u1 - u0) * (size_t)cout);
-    const int64_t *ps = km->pstart + (size_t)t * (K + 1);
+    const int32_t *ps = km->pstart + (size_t)t * (K + 1);
+    const int32_t *pin = km->tin[t], *pout = km->tout[t];
     for (int k = 0; k < K; ++k) {
       const float *Wk = W + (size_t)k * cin * cout;
-      for (int64_t p = ps[k]; p < ps[k + 1]; ++p)
-        row_gemm_acc(in + (size_t)km->pin[p] * ldi, cin, Wk, cout, out + (size_t)km->pout[p] * cout);
+      for (int32_t p = ps[k]; p < ps[k + 1]; ++p)
+        row_gemm_acc(in + (size_t)pin[p] * ldi, cin, Wk, cout, out + (size_t)pout[p] * cout);
     }
   }
 }
