@@ -259,7 +259,23 @@ class DeviceItemLoader:
             cx = models.get_context(self.device.index or 0, torch.cuda.current_stream().cuda_stream)
             if self._submap is None or self._submap.ctx is not cx:
                 self._submap = DeviceRadiusSubmap(self.map[:, :3], self.cfg["MODEL"]["VOXEL_SIZE"], device=self.device, ctx=cx)
+                self._calibrate_rows()
         return cx
+
+    def _calibrate_rows(self, samples: int = 4) -> None:
+        """Item rows per scan point of THIS map, from the radius query of a few sample scans (1.25 x the largest (n + m) / n,
+        as ScanEngine.calibrate_rows): a map at the network's voxel size gives ~6, so the default of 2.5 made the first
+        batch of every run overflow its buffer and run again.  One-off, synchronises."""
+        if not len(self.scans):
+            return
+        step = max(1, len(self.scans) // samples)
+        worst = 1.0
+        for s in list(self.scans)[::step][:samples]:
+            s = np.asarray(s)
+            if len(s):
+                _, counts = self._submap.query(s[:, :3])
+                worst = max(worst, 1.0 + float(counts.sum().item()) / len(s))
+        self.row_factor = max(self.row_factor, 1.25 * worst)
 
     def collate(self, idxs) -> torch.Tensor:
         """[sum N, 6] float32 device tensor = collate_fn([dataset[i] for i in idxs])."""
