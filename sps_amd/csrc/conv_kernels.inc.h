@@ -37,7 +37,7 @@ struct ConvArgs {
   float *fin_out;
   float fin_b;
   // rulebook of the level's 3x3x3x3 map (k_conv_px; built by k_maps): per supertile of 64 rows and time slice the chunk
-  // count, the offset of every chunk and 16 (input row << 6 | output row) entries per chunk
+  // count, the offset of every chunk and 16 (input row << 7 | output row) entries per chunk
   const uint32_t *rb_e;
   const unsigned char *rb_k;
   const int *rb_cnt;  // [supertiles][4]
@@ -582,7 +582,7 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
 //   execute in order: no atomics).  The private accumulators are summed in wave order by the epilogue:
 //   bit-reproducible.  Slots executed: 1.31 per pair instead of 2.3.  C_in = 8 layers (and the last 8 channels of
 //   C_in = 24) use 8-byte gathers and two MFMAs per chunk (lane group q = channels 2q, 2q + 1).
-//   Rulebook entry: (input row << 6) | output row inside the supertile; PAD entries gather zeros (OOR) into a
+//   Rulebook entry: (input row << 7) | output row inside the supertile; PAD entries (row 2^23 | 64) gather zeros (OOR) into a
 //   dummy accumulator row.  Per supertile: three segments (time slices), each with its chunk count, the offset of every
 //   chunk (1 byte) and 16 entries per chunk (map_kernels.inc.h).
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
@@ -653,6 +653,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   const uint32_t kwbytes = (uint32_t)a.upk * 256u;  // weights of one offset
   float *acc = acc_s[wave];
   const bool rmw = !C8 || q < 2;  // C_out <= 8: lane groups 2, 3 hold the zero-padded channels 8..15
+  const uint32_t accmul = rmw ? (uint32_t)AST : 0u, accadd = rmw ? 4u * (uint32_t)q : (uint32_t)(64 * AST + 4 * lane);
 
   for (int pos = blockIdx.x; pos < nst; pos += gridDim.x) {
     int4 ent = ent_first;
@@ -711,17 +712,21 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       const int lc = c - (c < n0 ? 0 : (c < n01 ? n0 : n01));  // chunk inside its segment
       const bool on = t < nbw && c < nch;
       ev = __builtin_amdgcn_raw_buffer_load_b32(rsE, on ? (uint32_t)((seg * PX_SEG_CH + lc) * 16 + n) * 4u : OOR, 0, 0);
+      ev = on ? ev : PX_PAD;  // chunks past the end of the list: padding (decided once per block, not per chunk)
       const int ck = 4 * (wave + NW * t) + lane;  // lanes 0..3: the block's four offset bytes
       const int segk = ck < n0 ? 0 : (ck < n01 ? 1 : 2);
       const int lck = ck - (ck < n0 ? 0 : (ck < n01 ? n0 : n01));
-      kv = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsK, (lane < 4 && t < nbw && ck < nch) ? (uint32_t)(segk * 112 + lck) : OOR, 0, 0);
+      const bool onk = lane < 4 && t < nbw && ck < nch;
+      kv = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rsK, onk ? (uint32_t)(segk * 112 + lck) : OOR, 0, 0);
+      kv = onk ? kv * kwbytes : 0x80000000u;  // byte offset of the chunk's weights (out of range for a chunk that is not there)
     };
     auto issue = [&](PxOperands<1> &r, uint32_t ev, uint32_t kv, int t, int j) {
-      const bool on = t < nbw && 4 * (wave + NW * t) + j < nch;  // wave-uniform
-      const uint32_t ew = (uint32_t)__shfl((int)ev, 16 * j + n, 64);
-      r.e[0] = on ? ew : PX_PAD;
-      const uint32_t wk = on ? (uint32_t)__builtin_amdgcn_readlane((int)kv, j) * kwbytes : 0x80000000u;
-      const uint32_t ioff = r.e[0] == PX_PAD ? OOR : __umul24(r.e[0] >> 6, ldi4);  // (rows < 2^23, row bytes < 2^24)
+      (void)t;
+      // no test for padding or for "is there a chunk": a PAD entry's row 2^23 is out of range by construction (zeros), its
+      // accumulator row 64 is the dummy, and fetch() turned chunks past the end into PAD entries / out-of-range weights
+      r.e[0] = (uint32_t)__shfl((int)ev, 16 * j + n, 64);
+      const uint32_t wk = (uint32_t)__builtin_amdgcn_readlane((int)kv, j);
+      const uint32_t ioff = __umul24(r.e[0] >> 7, ldi4);  // (rows <= 2^23, row bytes < 2^9)
       if (W128) {
         if (QUAD) {
           // quad-contiguous gather: lane l fetches unit l & 3 of pair l >> 2, so the four lanes of a quad read ONE 64-byte
@@ -729,7 +734,7 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
           // ds_bpermute.  Measured: block7.conv1 (C_in = 24) 25.0 -> 22.2 us, block8.conv1 (C_in = 16) 31.8 -> 33.6 us --
           // only the C_in = 24 instantiation uses it
           const uint32_t eq = (uint32_t)__shfl((int)ev, 16 * j + (lane >> 2), 64);
-          const uint32_t ioq = (!on || eq == PX_PAD) ? OOR : __umul24(eq >> 6, ldi4);
+          const uint32_t ioq = __umul24(eq >> 7, ldi4);
           r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioq + (uint32_t)(lane & 3) * 16u, 0, 0);
         } else {
           r.va[0] = __builtin_amdgcn_raw_buffer_load_b128(rsA, ioff + ga128, 0, 0);
@@ -742,14 +747,9 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       }
     };
     auto compute = [&](const PxOperands<1> &r) {
-      floatx4 *ap;
-      if (C8) {  // every lane updates SOME slot: its pair's row (lane groups 0, 1 of a real pair) or its own dummy slot
-        const bool real = r.e[0] != PX_PAD && q < 2;
-        ap = reinterpret_cast<floatx4 *>(acc + (real ? (int)(r.e[0] & 63u) * AST + 4 * q : 64 * AST + 4 * lane));
-      } else {
-        const int orow = r.e[0] == PX_PAD ? 64 : (int)(r.e[0] & 63u);
-        ap = reinterpret_cast<floatx4 *>(acc + orow * AST + 4 * q);
-      }
+      // every lane updates SOME slot: row (e & 127) of the accumulator -- 64 = the dummy row of a PAD entry -- at its four
+      // channels; C_out <= 8: the lane groups 2, 3 (zero-padded channels) their own dummy slot (row multiplier 0)
+      floatx4 *ap = reinterpret_cast<floatx4 *>(acc + __umul24(r.e[0] & 127u, accmul) + accadd);
       floatx4 cur = *ap;
       floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
       if (W128) {

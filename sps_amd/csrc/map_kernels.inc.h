@@ -47,8 +47,10 @@ struct MapsArgs {
 };
 
 // Rulebook layout per SUPERTILE of 64 output rows: three segments (one per time slice dt = -1, 0, +1) of up to PX_SEG_CH
-// chunks; a chunk = 16 entries (input row << 6 | output row inside the supertile) of ONE offset, padded with PX_PAD.
-constexpr uint32_t PX_PAD = 0xFFFFFFFFu;
+// chunks; a chunk = 16 entries (input row << 7 | output row inside the supertile, 0..63) of ONE offset, padded with PX_PAD.
+// PX_PAD = input row 2^23 (rows < 2^23: its byte offset lies beyond any feature buffer, the gather returns zeros) and
+// output row 64 (the dummy accumulator row): k_conv_px needs NO test for padding (round 4).
+constexpr uint32_t PX_PAD = (1u << 30) | 64u;
 constexpr int PX_SEG_CH = 108;   // chunks of a segment: 27 offsets x (64 rows / 16)
 constexpr int PX_CH_MAX = 324;   // chunks of a supertile
 constexpr int PX_KSTRIDE = 336;  // bytes of the chunk -> offset table of a supertile (3 x 112)
@@ -193,7 +195,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
             // without one write the padding behind the entries (there are always enough: cnt > 48 => 64 - cnt = the padding)
             const int cnt = __popcll(bal);
             const int pos = row >= 0 ? __popcll(bal & ltm) : cnt + __popcll(~bal & ltm);
-            if (row >= 0 || pos < ((cnt + 15) & ~15)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 6) | (uint32_t)lane : PX_PAD;
+            if (row >= 0 || pos < ((cnt + 15) & ~15)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 7) | (uint32_t)lane : PX_PAD;
             cb += (cnt + 15) >> 4;
             // chunk -> offset table: chunk q belongs to offset #{j' : chunks up to and including j' <= q}, counted per lane for
             // q = lane and q = lane + 64 and stored once at the end
@@ -354,13 +356,13 @@ __global__ void k_export_rulebook(const uint32_t *__restrict__ rb_e, const unsig
     const uint32_t e = rb_e[((size_t)st * PX_CH_MAX + (size_t)seg * PX_SEG_CH + lc) * 16 + j];
     if (e == PX_PAD) continue;
     const int k = rb_k[(size_t)st * PX_KSTRIDE + seg * 112 + lc];
-    const int u = st * 64 + (int)(e & 63u);
+    const int u = st * 64 + (int)(e & 127u);
     atomicAdd(&entries[0], 1ull);
     if (u >= n || k >= 81 || k / 27 != seg) {  // malformed entry
       atomicAdd(&entries[1], 1ull);
       continue;
     }
-    if (atomicExch(&out[(size_t)k * n + u], (int)(e >> 6)) != -1) atomicAdd(&entries[1], 1ull);
+    if (atomicExch(&out[(size_t)k * n + u], (int)(e >> 7)) != -1) atomicAdd(&entries[1], 1ull);
   }
 }
 
