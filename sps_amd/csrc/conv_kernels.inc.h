@@ -344,11 +344,15 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
       }
       const uint32_t qa = (uint32_t)q * 16u, qw = (uint32_t)q * wunit + wlane;
       uint32_t p_sa = 0u, p_sw = 0u;  // fast path: the group's scalar byte offsets (input row, weights)
+      int lks = -1;                  // offset whose LDS words (row byte offset, weight byte offset) are in p_aov / p_wov
       auto prep4 = [&](int jg) {
         p_val = jg < ju1;            // wave-uniform
-        const int kkc = min(ks, KCHUNK - 1);
-        p_aov = ao[kkc * 16 + r];
-        p_wov = wo[kkc];
+        if (ks != lks) {             // (scalar test: the C_in / 16 groups of an offset share one pair of LDS reads)
+          const int kkc = min(ks, KCHUNK - 1);
+          p_aov = ao[kkc * 16 + r];
+          p_wov = wo[kkc];
+          lks = ks;
+        }
         p_sa = (uint32_t)cs * 16u, p_sw = (uint32_t)cs * wunit;
         cs += 4;
         if (cs >= upk) cs = 0, ++ks;
