@@ -149,6 +149,7 @@ def main():
                          "rate, 7 reach 99 %%, 23 cost 3x the arena memory for +1 %%).  Short runs use fewer so that every stream "
                          "executes about three timed steps.  The HIP runtime multiplexes streams onto 4 hardware queues: counts "
                          "of the form 4k+3 measure 5-15 %% above their neighbours")
+    ap.add_argument("--exact-streams", action="store_true", help="DIAGNOSTIC: use exactly --streams streams even for short runs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank control flow on a single GPU)")
     ap.add_argument("--force-dist", action="store_true", help="initialise the process group and run the metric all-gather even at "
@@ -222,7 +223,7 @@ def main():
     # every stream should execute ~3 timed steps (a run of K steps on K streams measures the fill + drain of K one-step
     # pipelines): K = 20 -> 7 streams, K < 18 -> 3
     S = max(1, min(args.streams, K))
-    if S > 3 and K < 2.5 * S:
+    if S > 3 and K < 2.5 * S and not args.exact_streams:
         S = 7 if (args.streams >= 7 and K >= 18) else 3
     eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb, stage_cols=0 if args.no_h2d else 6)
     streams = eng.streams
