@@ -51,6 +51,7 @@ struct MapsArgs {
 // PX_PAD = input row 2^23 (rows < 2^23: its byte offset lies beyond any feature buffer, the gather returns zeros) and
 // output row 64 (the dummy accumulator row): k_conv_px needs NO test for padding (round 4).
 constexpr uint32_t PX_PAD = (1u << 30) | 64u;
+static_assert(SPS_MAX_POINTS <= (1 << 23), "PX_PAD's input row 2^23 must lie beyond every feature buffer (row capacity <= SPS_MAX_POINTS)");
 constexpr int PX_SEG_CH = 108;   // chunks of a segment: 27 offsets x (64 rows / 16)
 constexpr int PX_CH_MAX = 324;   // chunks of a supertile
 constexpr int PX_KSTRIDE = 336;  // bytes of the chunk -> offset table of a supertile (3 x 112)
