@@ -371,7 +371,14 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
 #endif
         va[g] = __builtin_amdgcn_raw_buffer_load_b128(rsA, oa, 0, 0);
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+        for (int nt = 0; nt < NTW; ++nt) {
+#if defined(SPS_ABLATE_SKIP_B)
+          // DIAGNOSTIC (wrong results): every second column tile re-uses its neighbour's weight fragment -- the wave-load COUNT
+          // of a tiling that shares one B fragment between two column tiles' worth of rows (32 x 32 x 2), MFMA work unchanged
+          if (nt & 1) { vb[g][nt] = vb[g][nt - 1]; continue; }
+#endif
+          vb[g][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, ob + nt * 256u, 0, 0);
+        }
       };
 #if defined(SPS_ABLATE_LOOP)
       const bool run_loop = false;

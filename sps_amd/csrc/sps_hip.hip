@@ -46,6 +46,7 @@
 #undef SPS_ABLATE_A
 #undef SPS_ABLATE_B
 #undef SPS_ABLATE_HALF_B
+#undef SPS_ABLATE_SKIP_B
 #undef SPS_ABLATE_MFMA
 #undef SPS_ABLATE_LOOP
 #undef SPS_ABLATE_STAGE
