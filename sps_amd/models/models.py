@@ -71,15 +71,18 @@ class NativeBackboneModule(nn.Module):
         self.mark_weights_dirty()
         self._plan = None
 
-    @staticmethod
-    def _accept_lin_kernel_shapes(module, state_dict, prefix, *_):
-        """A ``kernel_size = 1`` kernel may arrive 3-D ``[1, C_in, C_out]`` or (lin_layout = out_in) as
-        ``[C_out, C_in]``: the stored MEMORY is kept, what it means is decided by ``me_conventions`` where the blob is packed."""
+    def _accept_lin_kernel_shapes(self, module, state_dict, prefix, *_):
+        """A ``kernel_size = 1`` kernel may arrive 3-D ``[1, C_in, C_out]`` (always accepted: same memory as the 2-D form) or,
+        ONLY when ``me_conventions.lin_layout == "out_in"`` has been declared, as ``[C_out, C_in]``: the stored MEMORY is kept,
+        what it means is decided where the blob is packed.  Any other shape still fails the strict load."""
+        out_in = self.me_conventions.lin_layout == "out_in"
         for name, p in module.named_parameters():
             key = prefix + name
             if name.endswith(".kernel") and p.dim() == 2 and key in state_dict:
                 t = state_dict[key]
-                if t.shape != p.shape and t.numel() == p.numel():
+                squeezed = t.dim() == 3 and t.shape[0] == 1 and tuple(t.shape[1:]) == tuple(p.shape)
+                swapped = out_in and t.dim() == 2 and tuple(t.shape) == tuple(p.shape)[::-1]
+                if t.shape != p.shape and (squeezed or swapped):
                     state_dict[key] = t.reshape(p.shape)
 
     def blob_permutation(self):

@@ -96,3 +96,6 @@ def test_module_carries_the_conventions_and_accepts_lin_kernel_shapes():
     np.testing.assert_array_equal(got.reshape(-1).numpy(), stored.reshape(-1).numpy())
     net.model.set_me_conventions(None)
     assert net.model.blob_permutation() is None
+    # without the declared lin_layout a transposed 2-D kernel is a shape error, as in the reference's strict load
+    with pytest.raises(RuntimeError):
+        SPSNet(CFG).load_state_dict(sd)
