@@ -32,6 +32,11 @@ struct TOp {
 
 }  // namespace
 
+struct WgPlan {  // k_wgrad<aw, bw> over (nwg, K, zblocks) workgroups; nwg > 1: partials in slab + slab_off, reduced at the end
+  int aw = 1, bw = 1, zblocks = 1, NB = 1, nwg = 1, gshift = 6;
+  int64_t slab_off = 0;
+};
+
 struct sps_train {
   int64_t cap = 0;
   uint64_t arena_gen = 0;  // generation of the context's arena the views below point into
@@ -45,10 +50,11 @@ struct sps_train {
   size_t gpool_bytes = 0;
   float *r_p[9] = {}, *r_g[9] = {};        // BN'd 1x1 downsample branch (the residual operand) of block i (2..8)
   float *dz = nullptr;                     // scratch: gradient wrt a raw conv output [cap, 64]
-  float *slab = nullptr;
+  float *slab = nullptr;                   // workgroup partials of the weight gradients, every layer its own region
   size_t slab_floats = 0;
+  std::vector<WgPlan> wg;                  // per conv: geometry of its k_wgrad launch
   double *bn_part = nullptr, *bn_bpart = nullptr, *fin_part = nullptr;
-  float *bn_fin = nullptr, *bn_bfin = nullptr;  // per BN [2][BN_MAXC]: mean, invstd / scratch [2][BN_MAXC]: mean(dA), mean(dA xhat)
+  float *bn_fin = nullptr;                 // per BN [2][BN_MAXC]: mean, invstd
   float *batch_stats = nullptr;            // per BN [2][C] at 2 * ss_off-like offsets (same as c->ss layout)
   float *ones = nullptr, *zeros = nullptr;
   float *c0part = nullptr;
@@ -92,6 +98,8 @@ std::vector<FeatDesc> feat_list(sps_ctx *c) {
           {c->b7o, 16, 1},  {c->x2, 8, 2},  {c->b2t, 16, 2}, {c->cat6, 48, 2}, {c->b6t, 32, 2}, {c->b6o, 32, 2}, {c->x3, 16, 3},
           {c->b3t, 32, 3},  {c->cat5, 96, 3}, {c->b5t, 64, 3}, {c->b5o, 64, 3}, {c->x4, 32, 4}, {c->b4t, 64, 4}, {c->b4o, 64, 4}};
 }
+
+std::vector<TOp> train_ops(sps_ctx *c);
 
 int train_reserve(sps_ctx *c) {
   if (!c->train) c->train = new sps_train();
@@ -150,8 +158,41 @@ int train_reserve(sps_ctx *c) {
     TALLOC(t->r_p[b], float, (size_t)cap * rcols[b]);
   }
   TALLOC(t->dz, float, (size_t)cap * 64);
-  t->slab_floats = (size_t)81 * 24 * 16 * 256;  // K * (MT * NT <= 24) * nchunk (<= 16) tiles of 16 x 16
-  TALLOC(t->slab, float, t->slab_floats);
+  // weight gradients: a wave owns aw x bw tiles of 16 x 16 of dW[k] and one chunk of the level's row tiles; the rows are cut
+  // into nwg x 16 chunks so that ~16 k waves exist whatever the layer's K x block count (every wave walks its chunk as a
+  // chain of dependent loads: short chunks also bound the launch's duration), with at least ~128 rows per chunk at the row
+  // count a level typically has (a prior: the real count is only known on the device; it does not affect results beyond
+  // the summation order, which stays fixed for a given capacity)
+  {
+    static const double level_prior[SPS_NUM_LEVELS] = {1.0, 0.5, 0.2, 0.06, 0.02};
+    const char *wenv = getenv("SPS_WGRAD_WAVES");  // tuning knob: waves a weight-gradient launch aims for
+    const int64_t wave_target = wenv && atoi(wenv) > 0 ? atoi(wenv) : 16384;
+    t->wg.assign(s.convs.size(), WgPlan{});
+    int64_t off = 0;
+    for (const TOp &op : train_ops(c)) {
+      if (op.kind == T_CONV0) continue;
+      const int i = s.find_conv(op.name);
+      const ConvSpec &cs = s.convs[i];
+      const int level = op.kind == T_UP ? op.out.level + 1 : op.out.level;  // the level whose rows the map lists
+      WgPlan &w = t->wg[i];
+      w.aw = cs.cin >= 24 ? 2 : 1;
+      w.bw = cs.cout >= 64 ? 4 : cs.cout >= 32 ? 2 : 1;
+      w.NB = (cs.cout + 16 * w.bw - 1) / (16 * w.bw);
+      w.zblocks = ((cs.cin + 16 * w.aw - 1) / (16 * w.aw)) * w.NB;
+      const int64_t tiles = std::max<int64_t>(64, (int64_t)(level_prior[level] * (double)cap) / 16);
+      // rows are read 64 at a time, 16 where pairs of 64-row groups would not make ~4 k waves (1x1 maps, coarse stride maps)
+      w.gshift = (int64_t)cs.K * w.zblocks * (tiles / 8) < 4096 ? 4 : 6;
+      const int64_t groups = w.gshift == 4 ? tiles : tiles / 4;
+      const int64_t want = std::min<int64_t>(1024, std::max<int64_t>(WG_WAVES, wave_target / ((int64_t)cs.K * w.zblocks)));
+      int nwg = (int)((want + WG_WAVES - 1) / WG_WAVES);
+      while (nwg > 1 && (int64_t)nwg * WG_WAVES * (w.gshift == 4 ? 4 : 2) > groups) nwg >>= 1;
+      w.nwg = nwg;
+      w.slab_off = off;
+      if (nwg > 1) off += (int64_t)nwg * cs.K * cs.cin * cs.cout;
+    }
+    t->slab_floats = (size_t)off;
+    TALLOC(t->slab, float, t->slab_floats);
+  }
   TALLOC(t->bn_part, double, (size_t)s.bns.size() * BN_WG * 2 * BN_MAXC);
   TALLOC(t->bn_bpart, double, (size_t)BN_WG * 2 * BN_MAXC);
   TALLOC(t->fin_part, double, (size_t)BN_WG * 9);
@@ -159,7 +200,6 @@ int train_reserve(sps_ctx *c) {
     if (b.c < 8 || b.c > BN_MAXC || (b.c & (b.c - 1)))
       return fail(SPS_ERR_INVALID, "training BatchNorm kernels need 8 <= C <= %d, a power of two (got %d)", BN_MAXC, b.c);
   TALLOC(t->bn_fin, float, (size_t)s.bns.size() * 2 * BN_MAXC);
-  TALLOC(t->bn_bfin, float, (size_t)2 * BN_MAXC);
   TALLOC(t->batch_stats, float, s.ss_numel / 2 * 3);
   TALLOC(t->ones, float, 128);
   TALLOC(t->zeros, float, 128);
@@ -332,9 +372,15 @@ int conv_plain(sps_ctx *c, hipStream_t st, TKind gather, int level_rows, int K, 
   return launch_k_conv(a, g, false, grid, st);
 }
 
-int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, int cin, int cout, const float *x, int ldx,
-                 const float *dz, int ldz, float *dW) {
+template <int AW, int BW>
+void wgrad_go(const WgradArgs &w, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((k_wgrad<AW, BW>), grid, dim3(WG_WAVES * 64), 0, st, w);
+}
+
+int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int conv_index, int level_rows, int K, int cin, int cout, const float *x,
+                 int ldx, const float *dz, int ldz, float *dW) {
   sps_train *t = c->train;
+  const WgPlan &pl = t->wg[conv_index];
   WgradArgs w{};
   w.x = x;
   w.ldx = ldx;
@@ -343,11 +389,10 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
   w.K = K;
   w.cin = cin;
   w.cout = cout;
-  w.MT = (cin + 15) / 16;
-  w.NT = (cout + 15) / 16;
+  w.NB = pl.NB;
+  w.gshift = pl.gshift;
   w.ldn = c->capl[level_rows];
   w.n_rows = c->counts + level_rows;
-  w.slab = t->slab;
   Level &L = c->lv[level_rows];
   w.gather_b = kind == T_UP ? 1 : 0;
   if (kind == T_K3) {
@@ -357,21 +402,44 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int level_rows, int K, 
     w.nbr = L.down;
     w.tmask = L.tmdown;
   }
-  if (w.ldn % 16) return fail(SPS_ERR_INVALID, "wgrad: level capacity %lld is not a multiple of 16", (long long)w.ldn);
-  w.dW = dW;
-  // rows are cut into chunks of tiles, one per wave, 16 waves per workgroup (partial sums added in wave, then workgroup
-  // order): enough waves to fill the chip (~16 k) whatever the layer's K x tile count, and at least ~8 tiles per chunk;
-  // every wave walks its chunk as a chain of dependent loads, so short chunks also bound the launch's duration
-  const int64_t want = std::min<int64_t>(1024, std::max<int64_t>(WG_WAVES, 16384 / ((int64_t)K * w.MT * w.NT)));
-  int nwg = (int)((want + WG_WAVES - 1) / WG_WAVES);
-  const int64_t tiles_cap = (c->capl[level_rows] / 16);
-  while (nwg > 1 && (int64_t)nwg * WG_WAVES * 8 > tiles_cap) nwg >>= 1;
-  while ((size_t)K * w.MT * w.NT * nwg * 256 > t->slab_floats && nwg > 1) nwg >>= 1;
-  hipLaunchKernelGGL(k_wgrad, dim3((unsigned)nwg, (unsigned)K, (unsigned)(w.MT * w.NT)), dim3(WG_WAVES * 64), 0, st, w);
-  if (nwg > 1) {
-    const int total = K * cin * cout;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((total + 31) / 32)), dim3(256), 0, st, t->slab, K, cin, cout, w.MT, w.NT, nwg, dW);
+  if ((cin & 7) || (cout & 7) || (ldx & 3) || (ldz & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dz) & 15))
+    return fail(SPS_ERR_INVALID, "wgrad: operands must be 16-byte aligned with channel counts in multiples of 8");
+  w.out = pl.nwg > 1 ? t->slab + pl.slab_off : dW;
+  const dim3 grid((unsigned)pl.nwg, (unsigned)K, (unsigned)pl.zblocks);
+  const int key = pl.aw * 10 + pl.bw;
+  switch (key) {
+    case 11: wgrad_go<1, 1>(w, grid, st); break;
+    case 12: wgrad_go<1, 2>(w, grid, st); break;
+    case 14: wgrad_go<1, 4>(w, grid, st); break;
+    case 21: wgrad_go<2, 1>(w, grid, st); break;
+    case 22: wgrad_go<2, 2>(w, grid, st); break;
+    case 24: wgrad_go<2, 4>(w, grid, st); break;
+    default: return fail(SPS_ERR_INVALID, "wgrad: no instantiation for a %d x %d block", pl.aw, pl.bw);
   }
+  return SPS_OK;
+}
+
+// the one reduce launch of a backward: every layer whose k_wgrad ran with more than one workgroup per (k, block)
+int wgrad_reduce_all(sps_ctx *c, hipStream_t st) {
+  sps_train *t = c->train;
+  const NetSpec &s = *t->net;
+  WRedArgs r{};
+  int blk = 0;
+  for (size_t i = 0; i < s.convs.size(); ++i) {
+    const WgPlan &pl = t->wg[i];
+    if (pl.nwg <= 1) continue;
+    if (r.n >= WRED_MAX) return fail(SPS_ERR_INVALID, "wgrad: more than %d layers to reduce", WRED_MAX);
+    const ConvSpec &cs = s.convs[i];
+    WRedDesc &d = r.d[r.n++];
+    d.slab_off = pl.slab_off;
+    d.w_off = cs.w_off;
+    d.total = cs.K * cs.cin * cs.cout;
+    d.nwg = pl.nwg;
+    d.blk0 = blk;
+    d.nblk = std::min(256, (d.total + 255) / 256);
+    blk += d.nblk;
+  }
+  if (r.n) hipLaunchKernelGGL(k_wgrad_reduce_all, dim3((unsigned)blk), dim3(256), 0, st, r, t->slab, t->grad);
   return SPS_OK;
 }
 
@@ -440,10 +508,11 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
     if (!vec4_ok(z, cs.cout) || !vec4_ok(op.out.p, op.out.ld) || (op.res.p && !vec4_ok(op.res.p, op.res.ld)))
       return fail(SPS_ERR_INVALID, "training BatchNorm operands must be 16-byte aligned (%s)", op.name);
     hipLaunchKernelGGL(k_bn_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, z, cs.cout, c->counts + lo, cs.cout, part);
-    hipLaunchKernelGGL(k_bn_finish, dim3(1), dim3(BN_TPB), 0, st, part, c->counts + lo, cs.cout, fin, t->batch_stats + cs.ss_off / 2 * 3);
     const float *gamma = t->blob + bn.off, *beta = gamma + bn.c;
-    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 2048)), dim3(256), 0, st, z, cs.cout,
-                       c->counts + lo, cs.cout, fin, gamma, beta, op.res.p, op.res.ld, op.relu, op.out.p, op.out.ld);
+    // (every workgroup combines the partials itself: no finish launch in between)
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 1024)), dim3(256), 0, st, z, cs.cout,
+                       c->counts + lo, cs.cout, part, fin, t->batch_stats + cs.ss_off / 2 * 3, gamma, beta, op.res.p, op.res.ld,
+                       op.relu, op.out.p, op.out.ld);
   }
   // final 1x1 conv + bias, slice, sigmoid (models.py:28-29)
   const ConvSpec &fs = s.convs[s.find_conv("final")];
@@ -501,9 +570,21 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
   HIP_TRY(hipSetDevice(c->device));
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = t->n_last;
-  HIP_TRY(hipMemsetAsync(t->grad, 0, (size_t)numel * sizeof(float), st));
-  HIP_TRY(hipMemsetAsync(t->gpool, 0, t->gpool_bytes, st));
-  HIP_TRY(hipMemsetAsync(t->vacc, 0, (size_t)c->cap * sizeof(long long), st));
+  {  // gradients this backward accumulates into: the rows each level has, the parameter gradients, the logit accumulator
+    ZeroArgs z{};
+    int nz = 0;
+    auto add = [&](float *p, int64_t floats, int level) {
+      if (nz < ZERO_MAX) z.d[nz] = ZeroDesc{p, floats, level};
+      ++nz;
+    };
+    for (const TView &v : t->views) add(v.g, v.ld, v.level);
+    static const int rlevel[9] = {0, 0, 2, 3, 4, 3, 2, 1, 0}, rcols[9] = {0, 0, 16, 32, 64, 64, 32, 16, 8};
+    for (int b = 2; b <= 8; ++b) add(t->r_g[b], rcols[b], rlevel[b]);
+    add(t->grad, (numel + 3) & ~(int64_t)3, -1);  // (allocations are padded to 16 bytes)
+    add(reinterpret_cast<float *>(t->vacc), 2 * c->cap, -1);
+    if (nz > ZERO_MAX) return fail(SPS_ERR_INVALID, "backward: %d buffers to clear, table holds %d", nz, ZERO_MAX);
+    hipLaunchKernelGGL(k_zero_grads, dim3(96, (unsigned)nz), dim3(256), 0, st, z, c->counts, c->cap);
+  }
   // head: sigmoid + slice + final
   const ConvSpec &fs = s.convs[s.find_conv("final")];
   const TView b8o = view_of(t, c->b8o);
@@ -526,11 +607,9 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
     // BN (+ ReLU, + residual) backward: dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
     hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, op.out.g, op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout,
                        c->counts + lo, cs.cout, fin, t->bn_bpart);
-    hipLaunchKernelGGL(k_bn_bwd_finish, dim3(1), dim3(BN_TPB), 0, st, t->bn_bpart, c->counts + lo, cs.cout, t->bn_bfin, t->grad + bn.off,
-                       t->grad + bn.off + bn.c);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 2048)), dim3(256), 0, st, op.out.g,
-                       op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, fin, t->bn_bfin,
-                       t->blob + bn.off, t->dz, cs.cout, op.res.g, op.res.ld);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 1024)), dim3(256), 0, st, op.out.g,
+                       op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, fin, t->bn_bpart,
+                       t->blob + bn.off, t->grad + bn.off, t->grad + bn.off + bn.c, t->dz, cs.cout, op.res.g, op.res.ld);
     int rc = SPS_OK;
     if (op.kind == T_CONV0) {
       hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
@@ -539,20 +618,24 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
     }
     // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated
     if (op.kind == T_UP) {
-      rc = wgrad_launch(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+      rc = wgrad_launch(c, st, T_UP, ci, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
       if (rc != SPS_OK) return rc;
       // y[child] = x[parent] W[oct]  =>  dx[parent] += sum over children dy[child] W[oct]^T : a gather over the `down` table
       rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     } else if (op.kind == T_DOWN) {
-      rc = wgrad_launch(c, st, T_DOWN, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+      rc = wgrad_launch(c, st, T_DOWN, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
       if (rc != SPS_OK) return rc;
       // z[parent] = sum over children x[child] W[oct]  =>  dx[child] += dz[parent] W[oct]^T : parent-stationary scatter
       rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     } else {
-      rc = wgrad_launch(c, st, op.kind, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+      rc = wgrad_launch(c, st, op.kind, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
       if (rc != SPS_OK) return rc;
       rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     }
+    if (rc != SPS_OK) return rc;
+  }
+  {
+    const int rc = wgrad_reduce_all(c, st);
     if (rc != SPS_OK) return rc;
   }
   HIP_TRY(hipMemcpyAsync(grad_dev, t->grad, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));

@@ -86,36 +86,43 @@ __device__ inline void bn_block_reduce(BnAcc &s, int C, double (*red)[16][BN_MAX
     part[((size_t)blockIdx.x * 2 + w) * C + cc] = v;
   }
 }
-// k_bn_finish / k_bn_bwd_finish (one workgroup; a "last workgroup done" ticket inside the statistics kernel was measured:
-// the device-scope fence it needs writes back the XCD's L2 and cost 70 us per launch): sum the BN_WG partials of channel c
-// in index order.  1024 / C threads per channel take contiguous runs of partials, the runs meet in LDS in run order.
-// Returns the two sums in (t0, t1) for threads < C.
-__device__ inline void bn_combine(const double *__restrict__ vp, int C, double (*red)[16][BN_MAXC], double &t0, double &t1) {
-  double *r0 = &red[0][0][0], *r1 = &red[1][0][0];  // [BN_TPB / C runs][C] each (1024 doubles = the size of red[w])
-  const int c = threadIdx.x % C, run = threadIdx.x / C, per = BN_WG / (BN_TPB / C);
+// The BN_WG partials of a channel are combined by EVERY workgroup of the kernel that applies the statistics (k_bn_apply /
+// k_bn_bwd_apply; 256 threads): 256 / C threads per channel add contiguous runs of partials, the runs meet in LDS in run
+// order -- the same fixed order in every workgroup, so all of them hold identical values and workgroup 0 publishes them
+// (mean / invstd for the backward, batch statistics, dgamma / dbeta).  Rounds 2-4 ran one-workgroup k_bn_finish /
+// k_bn_bwd_finish launches between the passes: 64 launches x 5.1 us per training step for a few KB of arithmetic.  (A "last
+// workgroup done" ticket inside the statistics kernel was measured in round 2: the device-scope fence it needs writes
+// back the XCD's L2 and cost 70 us per launch.)  Levels with few rows use fewer partials (bn_parts: both kernels derive
+// the count from the same device-side row count).
+__device__ inline int bn_parts(int n) { return n >= 32768 ? BN_WG : 32; }
+// Returns the two sums in (t0, t1) for threads < C.  blockDim.x == 256; red: [2][256] doubles.
+__device__ inline void bn_combine(const double *__restrict__ vp, int nparts, int C, double (*red)[256], double &t0, double &t1) {
+  const int c = threadIdx.x % C, run = threadIdx.x / C, runs = 256 / C, per = nparts / runs;  // nparts >= 32 >= runs
   double s0 = 0, s1 = 0;
   for (int w = run * per; w < (run + 1) * per; ++w) {
     s0 += vp[((size_t)w * 2 + 0) * C + c];
     s1 += vp[((size_t)w * 2 + 1) * C + c];
   }
-  r0[run * C + c] = s0;
-  r1[run * C + c] = s1;
+  red[0][run * C + c] = s0;
+  red[1][run * C + c] = s1;
   __syncthreads();
   t0 = t1 = 0;
   if (threadIdx.x < (unsigned)C)
-    for (int q = 0; q < BN_TPB / C; ++q) {
-      t0 += r0[q * C + threadIdx.x];
-      t1 += r1[q * C + threadIdx.x];
+    for (int q = 0; q < runs; ++q) {
+      t0 += red[0][q * C + threadIdx.x];
+      t1 += red[1][q * C + threadIdx.x];
     }
 }
 
-// pass 1: per channel sum z and sum z^2 (k_bn_stats) -> fin[0][c] = mean, fin[1][c] = invstd + the batch statistics the
-// host folds into running_mean / running_var: mean, biased var, unbiased var (k_bn_finish)
+// pass 1: per channel sum z and sum z^2 (k_bn_stats); pass 2 (k_bn_apply) turns them into fin[0][c] = mean, fin[1][c] =
+// invstd + the batch statistics the host folds into running_mean / running_var: mean, biased var, unbiased var
 __global__ __launch_bounds__(BN_TPB) void k_bn_stats(const float *__restrict__ Z, int ld, const int *__restrict__ n_rows, int C,
                                                       double *__restrict__ part /* [BN_WG][2][C] */) {
   __shared__ double red[2][16][BN_MAXC];
   const int n = *n_rows;
-  const int per = (n + BN_WG - 1) / BN_WG;
+  const int W = bn_parts(n);
+  if ((int)blockIdx.x >= W) return;
+  const int per = (n + W - 1) / W;
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int CV = C >> 2, rpw = 64 / CV, cv = lane % CV, rsub = lane / CV;
@@ -131,37 +138,32 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_stats(const float *__restrict__ Z
   }
   bn_block_reduce(s, C, red, part);
 }
-__global__ __launch_bounds__(BN_TPB) void k_bn_finish(const double *__restrict__ part, const int *__restrict__ n_rows, int C,
-                                                       float *__restrict__ fin /* [2][BN_MAXC] */,
-                                                       float *__restrict__ batch_stats /* [3][C] */) {
-  __shared__ double red[2][16][BN_MAXC];
+// pass 2: y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] ), one float4 per thread step
+__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, int ldz, const int *__restrict__ n_rows, int C,
+                                                   const double *__restrict__ part, float *__restrict__ fin /* [2][BN_MAXC] */,
+                                                   float *__restrict__ batch_stats /* [3][C] */, const float *__restrict__ gamma,
+                                                   const float *__restrict__ beta, const float *__restrict__ res, int ldr,
+                                                   int relu, float *__restrict__ Y, int ldy) {
+  __shared__ float sc[BN_MAXC], sh[BN_MAXC];
+  __shared__ double red[2][256];
   const int n = *n_rows;
   double s0, s1;
-  bn_combine(part, C, red, s0, s1);
+  bn_combine(part, bn_parts(n), C, red, s0, s1);
   if (threadIdx.x < (unsigned)C) {
     const int c = threadIdx.x;
     const double m = n > 0 ? s0 / n : 0.0;
     double var = n > 0 ? s1 / n - m * m : 0.0;
     if (var < 0) var = 0;
-    fin[c] = (float)m;
-    fin[BN_MAXC + c] = (float)(1.0 / sqrt(var + 1e-5));
-    batch_stats[c] = (float)m;
-    batch_stats[C + c] = (float)var;
-    batch_stats[2 * C + c] = (float)(n > 1 ? var * ((double)n / (double)(n - 1)) : var);  // what running_var accumulates
-  }
-}
-
-// pass 2: y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] ), one float4 per thread step
-__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, int ldz, const int *__restrict__ n_rows, int C,
-                                                   const float *__restrict__ fin, const float *__restrict__ gamma,
-                                                   const float *__restrict__ beta, const float *__restrict__ res, int ldr,
-                                                   int relu, float *__restrict__ Y, int ldy) {
-  __shared__ float sc[BN_MAXC], sh[BN_MAXC];
-  const int n = *n_rows;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const float mean = fin[c], invstd = fin[BN_MAXC + c];
+    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + 1e-5));
     sc[c] = invstd * gamma[c];
     sh[c] = beta[c] - mean * invstd * gamma[c];
+    if (blockIdx.x == 0) {
+      fin[c] = mean;
+      fin[BN_MAXC + c] = invstd;
+      batch_stats[c] = mean;
+      batch_stats[C + c] = (float)var;
+      batch_stats[2 * C + c] = (float)(n > 1 ? var * ((double)n / (double)(n - 1)) : var);  // what running_var accumulates
+    }
   }
   __syncthreads();
   const int lcv = __ffs(C) - 3, CV = C >> 2;
@@ -182,14 +184,16 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, i
 }
 
 // backward pass 1: dA = dY * (Y > 0 if relu); per channel sum dA and sum dA * xhat (xhat = (z - mean) * invstd)
-// (k_bn_bwd_stats) -> dbeta, dgamma and bfin[0][c] = mean(dA), bfin[1][c] = mean(dA * xhat) (k_bn_bwd_finish)
+// (k_bn_bwd_stats) -> dbeta, dgamma and mean(dA), mean(dA * xhat) (combined at the top of k_bn_bwd_apply)
 __global__ __launch_bounds__(BN_TPB) void k_bn_bwd_stats(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
                                                           int relu, const float *__restrict__ Z, int ldz,
                                                           const int *__restrict__ n_rows, int C, const float *__restrict__ fin,
                                                           double *__restrict__ bpart /* [BN_WG][2][C] */) {
   __shared__ double red[2][16][BN_MAXC];
   const int n = *n_rows;
-  const int per = (n + BN_WG - 1) / BN_WG;
+  const int W = bn_parts(n);
+  if ((int)blockIdx.x >= W) return;
+  const int per = (n + W - 1) / W;
   const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int CV = C >> 2, rpw = 64 / CV, cv = lane % CV, rsub = lane / CV;
@@ -221,37 +225,30 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_bwd_stats(const float *__restrict
   }
   bn_block_reduce(s, C, red, bpart);
 }
-__global__ __launch_bounds__(BN_TPB) void k_bn_bwd_finish(const double *__restrict__ bpart, const int *__restrict__ n_rows, int C,
-                                                           float *__restrict__ bfin /* [2][BN_MAXC] */, float *__restrict__ dgamma,
-                                                           float *__restrict__ dbeta) {
-  __shared__ double red[2][16][BN_MAXC];
-  const int n = *n_rows;
-  double s0, s1;
-  bn_combine(bpart, C, red, s0, s1);
-  if (threadIdx.x < (unsigned)C) {
-    const int c = threadIdx.x;
-    dbeta[c] = (float)s0;
-    dgamma[c] = (float)s1;
-    bfin[c] = n > 0 ? (float)(s0 / n) : 0.f;
-    bfin[BN_MAXC + c] = n > 0 ? (float)(s1 / n) : 0.f;
-  }
-}
-
 // backward pass 2: dZ = gamma * invstd * (dA - mean(dA) - xhat * mean(dA * xhat));
 // the masked gradient dA is also ADDED to dres (the gradient of the residual operand), when given.
 __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
                                                        int relu, const float *__restrict__ Z, int ldz,
                                                        const int *__restrict__ n_rows, int C, const float *__restrict__ fin,
-                                                       const float *__restrict__ bfin, const float *__restrict__ gamma,
+                                                       const double *__restrict__ bpart, const float *__restrict__ gamma,
+                                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                        float *__restrict__ dZ, int lddz, float *__restrict__ dres, int lddr) {
   __shared__ float mean_s[BN_MAXC], inv_s[BN_MAXC], k1_s[BN_MAXC], k2_s[BN_MAXC], gi_s[BN_MAXC];
+  __shared__ double red[2][256];
   const int n = *n_rows;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+  double s0, s1;
+  bn_combine(bpart, bn_parts(n), C, red, s0, s1);
+  if (threadIdx.x < (unsigned)C) {
+    const int c = threadIdx.x;
     mean_s[c] = fin[c];
     inv_s[c] = fin[BN_MAXC + c];
-    k1_s[c] = bfin[c];
-    k2_s[c] = bfin[BN_MAXC + c];
+    k1_s[c] = n > 0 ? (float)(s0 / n) : 0.f;
+    k2_s[c] = n > 0 ? (float)(s1 / n) : 0.f;
     gi_s[c] = gamma[c] * fin[BN_MAXC + c];
+    if (blockIdx.x == 0) {
+      dbeta[c] = (float)s0;
+      dgamma[c] = (float)s1;
+    }
   }
   __syncthreads();
   const int lcv = __ffs(C) - 3, CV = C >> 2;
@@ -288,125 +285,236 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // weight gradient of a sparse convolution: dW[k][ci][co] = sum over the pairs (i, o) of offset k of x[i][ci] * dz[o][co]
 // ------------------------------------------------------------------------------------------
-// One wave = one 16 x 16 tile (mt, nt) of dW[k] over one chunk of the map's rows; MFMA 16x16x4 with the PAIRS as the
-// contraction dimension: lane (m, q) feeds A[m][q] = x[i][16 mt + m] and B[q][n] = dz[o][16 nt + n] for row 4 q + s of the
-// tile in step s (so a lane's four map entries are ONE 16-byte load).  Tiles of 16 rows whose mask lacks offset k are
-// skipped: the wave first turns the mask words of (up to) 64 tiles into a ballot, then walks the set bits two tiles at a
-// time, all loads of both tiles issued together -- the chain per pair of tiles is map entry -> operand rows -> MFMA.
+// One wave = a block of AW x BW tiles of 16 x 16 of dW[k] over one chunk of the map's rows; MFMA 16x16x4 with the PAIRS as
+// the contraction dimension -- and only the pairs that EXIST:
+//   * the wave reads the map entries of 64 rows (16 for small maps) with one coalesced load (lane = row), ballots "has a neighbour at offset
+//     k" and appends the existing (input row, output row) pairs to a 128-entry ring in LDS (prefix popcount = position);
+//   * whenever the ring holds 32 pairs, two groups of 16 are consumed: lane (m, q) takes pairs 4 q + s (s = 0..3: one
+//     ds_read_b128 each of the input and output rows), gathers the AW input channels ca0 + AW m + a of x[i] (ONE AW-wide
+//     load) and the BW output channels cb0 + BW m + b of dz[o], and issues 4 AW BW MFMAs per group.  Leftover pairs stay in
+//     the ring for the next 64 rows: no padding except at the end of the chunk.
+// Tile (a, b) of the block holds dW[ca0 + AW mi + a][cb0 + BW ni + b]: the 16 x 16 tiles interleave over the channels so
+// that a row segment of 16 AW channels is read by 16 lanes as contiguous vectors.
+// (Rounds 2-3 walked 16-row tiles with at least one pair and multiplied all 16 rows, absent neighbours as zeros -- at the
+// fine levels a third of the slots -- with one 16 x 16 tile per wave: 8 dword loads for 4 MFMAs and every operand row
+// fetched again by each of the MT x NT waves; the coarse layers moved 11 TB/s through the L1s for 0.04 of the MFMA peak.)
 //   gather_b = 0: i = nbr[k][o], o = row      (3^4 convs and stride-2 convs: the map gathers the INPUT)
 //   gather_b = 1: i = row, o = nbr[k][row]    (transposed convs: the `down` table of the coarse level lists the OUTPUT rows)
 // The 16 waves of a workgroup take 16 consecutive chunks and add their tiles in LDS in wave order; with one workgroup per
-// (k, tile) the sum IS dW, otherwise it goes to slab[((k * MT + mt) * NT + nt) * nwg + wg][16][16] and k_wgrad_reduce adds
-// the workgroups in order.
+// (k, block) the sum IS dW, otherwise it goes to this launch's slab[wg][K][cin][cout] and k_wgrad_reduce_all (one launch
+// at the end of the backward, all layers) adds the workgroups in order.  Every order is fixed by the data, not by timing.
 struct WgradArgs {
   const float *x;   // [*, ldx] operand indexed by i
   const float *dz;  // [*, ldz] operand indexed by o
   const int *nbr;   // [K][ldn] or null (1x1: i = o = row)
-  const uint32_t *tmask;
+  const uint32_t *tmask;  // per 16-row tile, one word per time slice: the offsets for which the tile's table entries were WRITTEN
   const int *n_rows;  // rows of the map (device count)
-  float *slab;
-  float *dW;          // [K][cin][cout]
-  int64_t ldn;        // multiple of 16 (the host checks): a tile's map entries are in range and 16-byte aligned
-  int ldx, ldz, K, cin, cout, MT, NT, gather_b;
+  float *out;         // gridDim.x == 1: dW [K][cin][cout]; otherwise the launch's slab [gridDim.x][K][cin][cout]
+  int64_t ldn;
+  int ldx, ldz, K, cin, cout, NB, gather_b;  // NB: blocks of 16 BW output channels (blockIdx.z = input block * NB + output block)
+  int gshift;  // rows a wave reads per step = the unit the chunks are cut in: 64 (6), or 16 (4) for maps too small to fill the chip in 64s
 };
 constexpr int WG_WAVES = 16;
+constexpr int WG_RING = 128;  // pairs a wave can hold: <= 31 left over + 64 new
 
-struct WgradTile {
-  float av[4], bv[4];
-};
-__device__ inline void wgrad_load(const WgradArgs &a, int t, int k, int n, int q, int ca, int cb, bool va, bool vb, WgradTile &w) {
-  const int row0 = t * 16 + 4 * q;
-  int other[4] = {row0, row0 + 1, row0 + 2, row0 + 3};
-  if (a.nbr && t >= 0) {
-    const int4 e = *reinterpret_cast<const int4 *>(a.nbr + (size_t)k * a.ldn + row0);
-    other[0] = e.x, other[1] = e.y, other[2] = e.z, other[3] = e.w;
-  }
-#pragma unroll
-  for (int s = 0; s < 4; ++s) {
-    const int row = row0 + s;
-    const bool in = t >= 0 && row < n;
-    const int i = a.gather_b ? row : other[s];
-    const int o = a.gather_b ? other[s] : row;
-    const bool ok = in && i >= 0 && o >= 0;
-    w.av[s] = (ok && va) ? a.x[(size_t)i * a.ldx + ca] : 0.f;
-    w.bv[s] = (ok && vb) ? a.dz[(size_t)o * a.ldz + cb] : 0.f;
+template <int W>
+__device__ inline void wgrad_ldvec(const float *__restrict__ p, bool ok, float (&v)[W]) {
+#if defined(SPS_WG_ABLATE_GATHER)
+  for (int i = 0; i < W; ++i) v[i] = ok ? 1.f : 0.f;
+  return;
+#endif
+  if constexpr (W == 1) {
+    v[0] = ok ? *p : 0.f;
+  } else if constexpr (W == 2) {
+    const float2 t = ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
+    v[0] = t.x, v[1] = t.y;
+  } else {
+    static_assert(W == 4, "operand vectors are 1, 2 or 4 floats");
+    const float4 t = ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
   }
 }
+template <int AW, int BW>
+struct WgradGroup {  // the operands of 16 pairs
+  float av[4][AW], bv[4][BW];
+};
+// pairs [base + 4 q, base + 4 q + 4) of the ring (base a multiple of 16); those at or beyond `end` contribute zeros
+template <int AW, int BW>
+__device__ inline void wgrad_gather(const WgradArgs &a, const int *__restrict__ qi, const int *__restrict__ qo, int base, int end, int q,
+                                    int ca, int cb, bool va, bool vb, WgradGroup<AW, BW> &w) {
+  const int p0 = base + 4 * q;
+  const int4 iv = *reinterpret_cast<const int4 *>(qi + (p0 & (WG_RING - 1)));
+  const int4 ov = *reinterpret_cast<const int4 *>(qo + (p0 & (WG_RING - 1)));
+  const int in[4] = {iv.x, iv.y, iv.z, iv.w}, out[4] = {ov.x, ov.y, ov.z, ov.w};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bool ok = p0 + s < end;
+    wgrad_ldvec<AW>(a.x + (size_t)in[s] * a.ldx + ca, ok && va, w.av[s]);
+    wgrad_ldvec<BW>(a.dz + (size_t)out[s] * a.ldz + cb, ok && vb, w.bv[s]);
+  }
+}
+template <int AW, int BW>
+__device__ inline void wgrad_mfma(const WgradGroup<AW, BW> &w, floatx4 (&acc)[AW][BW]) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int i = 0; i < AW; ++i)
+#pragma unroll
+      for (int j = 0; j < BW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(w.av[s][i], w.bv[s][j], acc[i][j], 0, 0, 0);
+}
 
+template <int AW, int BW>
 __global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
   __shared__ float red[WG_WAVES][256];
+  __shared__ __attribute__((aligned(16))) int q_in[WG_WAVES][WG_RING], q_out[WG_WAVES][WG_RING];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int n = *a.n_rows;
-  const int ntiles = (n + 15) >> 4;
+  const int gshift = a.gshift, grows = 1 << gshift;
+  const int ngroups = (n + grows - 1) >> gshift;
   const int k = blockIdx.y;
-  const int tile_id = blockIdx.z;  // mt * NT + nt
-  const int mt = tile_id / a.NT, nt = tile_id - mt * a.NT;
+  const int ab = (int)blockIdx.z / a.NB, bb = (int)blockIdx.z - ab * a.NB;
   const int nchunk = (int)gridDim.x * WG_WAVES;
   const int chunk = blockIdx.x * WG_WAVES + wave;
-  const int per = (ntiles + nchunk - 1) / nchunk;
-  const int t0 = chunk * per, t1 = min(ntiles, t0 + per);
-  const int ca = mt * 16 + m, cb = nt * 16 + m;
-  const bool va = ca < a.cin, vb = cb < a.cout;
+  const int per = (ngroups + nchunk - 1) / nchunk;
+  const int g0 = chunk * per, g1 = min(ngroups, g0 + per);
+  const int ca0 = ab * 16 * AW, cb0 = bb * 16 * BW;
+  const int ca = ca0 + AW * m, cb = cb0 + BW * m;
+  const bool va = ca < a.cin, vb = cb < a.cout;  // channel counts are multiples of 8: a vector is inside or outside as a whole
+  int *__restrict__ qi = q_in[wave], *__restrict__ qo = q_out[wave];
+  const int *__restrict__ tab = a.nbr ? a.nbr + (size_t)k * a.ldn : nullptr;
+  floatx4 acc[AW][BW];
+#pragma unroll
+  for (int i = 0; i < AW; ++i)
+#pragma unroll
+    for (int j = 0; j < BW; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
   const int kw = k / 27, kb = k % 27;  // one mask word per time slice (27 offsets); K = 8 maps: word 0
-  floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
-  for (int tb = t0; tb < t1; tb += 64) {
-    const int tl = tb + lane;
-    bool present = tl < t1;
-    if (present && a.tmask) present = (a.tmask[(size_t)tl * 4 + kw] >> kb) & 1u;
-    uint64_t bm = __ballot(present);
-    while (bm) {
-      const int ta = tb + __builtin_ctzll(bm);
-      bm &= bm - 1;
-      const int tc = bm ? tb + __builtin_ctzll(bm) : -1;
-      bm &= bm - 1;  // 0 & anything = 0
-      WgradTile u, v;
-      wgrad_load(a, ta, k, n, q, ca, cb, va, vb, u);
-      wgrad_load(a, tc, k, n, q, ca, cb, va, vb, v);
+  // (the map kernels leave the entries of a 16-row tile without any pair at offset k unwritten: the tile masks say which
+  // entries are real.)  The masks of 64 tiles at a time become one wave-uniform 64-bit word (a ballot), so the entry load
+  // of a step does not wait for a mask load of its own.
+  const int ntiles = (n + 15) >> 4;
+  uint64_t tm = ~0ull;
+  int tbase = -(1 << 30);
+  constexpr int WG_UNROLL = 4;  // groups whose entries are requested together (one exposed round trip per 4 groups)
+  auto cover = [&](int g) {  // make `tm` hold the tiles of groups g .. g + 3 (wave-uniform control flow)
+    if (!a.tmask || g >= g1) return;
+    const int t0 = (g << gshift) >> 4, t1 = t0 + WG_UNROLL * max(1, grows >> 4);
+    if (t0 >= tbase && t1 <= tbase + 64) return;
+    tbase = t0;
+    const int t = t0 + lane;
+    bool p = t < ntiles;
+    if (p) p = (a.tmask[(size_t)t * 4 + kw] >> kb) & 1u;
+    tm = __ballot(p);
+  };
+  auto entry = [&](int g) -> int {  // the neighbour of row (g << gshift) + lane at offset k (or -1)
+    const int row = (g << gshift) + lane;
+    if (g >= g1 || lane >= grows || row >= n) return -1;
+    if (a.tmask && !((tm >> ((row >> 4) - tbase)) & 1ull)) return -1;
+    return tab ? tab[row] : row;
+  };
+  int qh = 0, qt = 0;  // ring head / tail (wave-uniform, monotonic; position = index mod WG_RING)
+  int e_next[WG_UNROLL];
+  cover(g0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(u.av[s], u.bv[s], acc, 0, 0, 0);
+  for (int j = 0; j < WG_UNROLL; ++j) e_next[j] = entry(g0 + j);
+  for (int g = g0; g < g1; g += WG_UNROLL) {
+    int e_cur[WG_UNROLL];
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.av[s], v.bv[s], acc, 0, 0, 0);
+    for (int j = 0; j < WG_UNROLL; ++j) e_cur[j] = e_next[j];
+    cover(g + WG_UNROLL);
+#pragma unroll
+    for (int j = 0; j < WG_UNROLL; ++j) e_next[j] = entry(g + WG_UNROLL + j);  // requested before this step's operand rows are gathered
+#pragma unroll
+    for (int j = 0; j < WG_UNROLL; ++j) {
+      const int e = e_cur[j];
+      const bool valid = e >= 0;
+      const uint64_t bm = __ballot(valid);
+      if (!bm) continue;
+      if (valid) {
+        const int pos = (qt + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u))) & (WG_RING - 1);
+        const int row = ((g + j) << gshift) + lane;
+        qi[pos] = a.gather_b ? row : e;
+        qo[pos] = a.gather_b ? e : row;
+      }
+      qt += __popcll(bm);
+      __builtin_amdgcn_wave_barrier();
+      if constexpr (AW * BW >= 8) {  // (two groups of a 2 x 4 block in flight: 184 bytes of scratch per lane)
+        while (qt - qh >= 16) {
+          WgradGroup<AW, BW> u;
+          wgrad_gather<AW, BW>(a, qi, qo, qh, qt, q, ca, cb, va, vb, u);
+          wgrad_mfma<AW, BW>(u, acc);
+          qh += 16;
+        }
+      } else {
+        while (qt - qh >= 32) {
+          WgradGroup<AW, BW> u, v;
+          wgrad_gather<AW, BW>(a, qi, qo, qh, qt, q, ca, cb, va, vb, u);
+          wgrad_gather<AW, BW>(a, qi, qo, qh + 16, qt, q, ca, cb, va, vb, v);
+          wgrad_mfma<AW, BW>(u, acc);
+          wgrad_mfma<AW, BW>(v, acc);
+          qh += 32;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // the next entries are "used" here, where a wait for the gathers above has covered them anyway: the compiler then
+    // knows they are resident at the top of the next iteration instead of draining the queue (vmcnt(0)) right after
+    // requesting the entries after them
+#pragma unroll
+    for (int j = 0; j < WG_UNROLL; ++j) asm volatile("" : "+v"(e_next[j]));
+  }
+  if (qt > qh) {  // the chunk's last <= 31 (15) pairs
+    WgradGroup<AW, BW> u;
+    wgrad_gather<AW, BW>(a, qi, qo, qh, qt, q, ca, cb, va, vb, u);
+    wgrad_mfma<AW, BW>(u, acc);
+    if (AW * BW < 8 && qt - qh > 16) {
+      wgrad_gather<AW, BW>(a, qi, qo, qh + 16, qt, q, ca, cb, va, vb, u);
+      wgrad_mfma<AW, BW>(u, acc);
     }
   }
-  // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+  // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i.  The block's tiles go through LDS one after the other.
+  float *__restrict__ dst = a.out + ((size_t)blockIdx.x * a.K + k) * (size_t)(a.cin * a.cout);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) red[wave][(q * 4 + i) * 16 + m] = acc[i];
-  __syncthreads();
-  if (threadIdx.x < 256) {
-    const int e = threadIdx.x;
-    float sum = 0.f;
+  for (int ti = 0; ti < AW; ++ti)
 #pragma unroll
-    for (int w = 0; w < WG_WAVES; ++w) sum += red[w][e];
-    if (gridDim.x == 1) {
-      const int ci = mt * 16 + (e >> 4), co = nt * 16 + (e & 15);
-      if (ci < a.cin && co < a.cout) a.dW[((size_t)k * a.cin + ci) * a.cout + co] = sum;
-    } else {
-      a.slab[(((size_t)k * a.MT * a.NT + tile_id) * gridDim.x + blockIdx.x) * 256 + e] = sum;
+    for (int tj = 0; tj < BW; ++tj) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[wave][(q * 4 + i) * 16 + m] = acc[ti][tj][i];
+      __syncthreads();
+      if (threadIdx.x < 256) {
+        const int e = threadIdx.x;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < WG_WAVES; ++w) sum += red[w][e];
+        const int ci = ca0 + AW * (e >> 4) + ti, co = cb0 + BW * (e & 15) + tj;
+        if (ci < a.cin && co < a.cout) dst[(size_t)ci * a.cout + co] = sum;
+      }
+      __syncthreads();
     }
-  }
 }
 
-// 32 outputs per workgroup; 8 threads per output add every 8th workgroup partial (ascending), then meet in LDS in order
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ slab, int K, int cin, int cout, int MT, int NT, int nwg,
-                                                       float *__restrict__ dW /* [K][cin][cout] */) {
-  __shared__ float red[8][32];
-  const int total = K * cin * cout;
-  const int j = threadIdx.x >> 5, i = blockIdx.x * 32 + (threadIdx.x & 31);
-  float s = 0.f;
-  if (i < total) {
-    const int co = i % cout, ci = (i / cout) % cin, k = i / (cout * cin);
-    const int mt = ci >> 4, nt = co >> 4;
-    const float *src = slab + (((size_t)k * MT * NT + mt * NT + nt) * nwg) * 256 + (ci & 15) * 16 + (co & 15);
-    for (int c = j; c < nwg; c += 8) s += src[(size_t)c * 256];
-  }
-  red[j][threadIdx.x & 31] = s;
-  __syncthreads();
-  if (j == 0 && i < total) {
-    float v = red[0][threadIdx.x];
-#pragma unroll
-    for (int q = 1; q < 8; ++q) v += red[q][threadIdx.x];
-    dW[i] = v;
+// One launch at the end of the backward adds the workgroup partials of every layer whose weight gradient was cut into
+// more than one workgroup per (k, block): dW[i] = sum over wg (ascending) of slab[wg][i].  Rounds 2-4: one reduce launch
+// per layer (28 per step).
+struct WRedDesc {
+  int64_t slab_off;  // floats
+  int64_t w_off;     // into the gradient blob
+  int total, nwg, blk0, nblk;
+};
+constexpr int WRED_MAX = 40;
+struct WRedArgs {
+  WRedDesc d[WRED_MAX];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_wgrad_reduce_all(WRedArgs r, const float *__restrict__ slab, float *__restrict__ grad) {
+  int d = 0;
+  while (d + 1 < r.n && (int)blockIdx.x >= r.d[d + 1].blk0) ++d;
+  const WRedDesc &L = r.d[d];
+  const float *__restrict__ src = slab + L.slab_off;
+  for (int i = ((int)blockIdx.x - L.blk0) * 256 + (int)threadIdx.x; i < L.total; i += L.nblk * 256) {
+    float s = 0.f;
+    for (int w = 0; w < L.nwg; ++w) s += src[(size_t)w * L.total + i];
+    grad[L.w_off + i] = s;
   }
 }
 
@@ -527,6 +635,27 @@ __global__ void k_final_bwd_reduce(const double *__restrict__ part, float *__res
   for (int w = 0; w < BN_WG; ++w) s += part[(size_t)w * 9 + j];
   if (j < 8) dw[j] = (float)s;
   else db[0] = (float)s;
+}
+
+// Start of a backward: the gradient buffers it accumulates into go to zero -- only the rows a level HAS (device-side counts;
+// the arenas hold `cap` rows per buffer at every level: a hipMemset of the whole pool was 69 us per step at config 2) plus
+// the flat buffers (parameter gradients, the fixed-point logit accumulator).  blockIdx.y = buffer.
+struct ZeroDesc {
+  float *p;
+  int64_t floats;  // level < 0: this many floats; otherwise ld floats per row of the level
+  int level;
+};
+constexpr int ZERO_MAX = 32;
+struct ZeroArgs {
+  ZeroDesc d[ZERO_MAX];
+};
+__global__ __launch_bounds__(256) void k_zero_grads(ZeroArgs z, const int *__restrict__ counts, int64_t cap) {
+  const ZeroDesc &d = z.d[blockIdx.y];
+  int64_t n = d.floats;
+  if (d.level >= 0) n *= min(cap, ((int64_t)counts[d.level] + 63) & ~(int64_t)63);
+  float4 *__restrict__ p4 = reinterpret_cast<float4 *>(d.p);  // 16-byte aligned, float counts in multiples of 4 (the host checks)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * blockDim.x)
+    p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // nn.BatchNorm1d in training mode refuses a single value per channel (the reference's MinkowskiBatchNorm raises): a level
