@@ -391,6 +391,9 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int conv_index, int lev
   w.cout = cout;
   w.NB = pl.NB;
   w.gshift = pl.gshift;
+  // extents for the raw buffer loads (training runs on dense arenas: every level's buffers hold cap rows)
+  w.x_bytes = (uint32_t)((size_t)c->cap * (size_t)ldx * 4u);
+  w.dz_bytes = (uint32_t)((size_t)c->cap * (size_t)ldz * 4u);
   w.ldn = c->capl[level_rows];
   w.n_rows = c->counts + level_rows;
   Level &L = c->lv[level_rows];

@@ -312,26 +312,37 @@ struct WgradArgs {
   float *out;         // gridDim.x == 1: dW [K][cin][cout]; otherwise the launch's slab [gridDim.x][K][cin][cout]
   int64_t ldn;
   int ldx, ldz, K, cin, cout, NB, gather_b;  // NB: blocks of 16 BW output channels (blockIdx.z = input block * NB + output block)
+  uint32_t x_bytes, dz_bytes;  // extents of the operand buffers from x / dz on (raw buffer loads: an offset beyond them reads zeros)
   int gshift;  // rows a wave reads per step = the unit the chunks are cut in: 64 (6), or 16 (4) for maps too small to fill the chip in 64s
 };
 constexpr int WG_WAVES = 16;
 constexpr int WG_RING = 128;  // pairs a wave can hold: <= 31 left over + 64 new
 
-template <int W>
-__device__ inline void wgrad_ldvec(const float *__restrict__ p, bool ok, float (&v)[W]) {
+constexpr uint32_t WG_OOR = 0xFFFFFFFFu;
+// W floats at byte offset `off` of the buffer (WG_OOR: zeros).  Raw buffer loads: a gather is branch-free whatever the
+// lanes' validity, so the compiler can count the loads in flight (per-lane `if (ok) load` made every wait a vmcnt(0):
+// operand rows of the next group could not stay in flight under the MFMAs of the current one).
+template <int W, bool MASKED = false>
+__device__ inline void wgrad_ldvec(const __amdgpu_buffer_rsrc_t &rs, const float *__restrict__ base, uint32_t off, float (&v)[W]) {
+  if constexpr (MASKED) {  // per-lane `if (ok) load`: lanes without an operand issue nothing (1 x 1 blocks, see k_wgrad)
+    static_assert(W == 1, "masked loads are for single floats");
+    v[0] = off != WG_OOR ? *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + off) : 0.f;
+    return;
+  }
 #if defined(SPS_WG_ABLATE_GATHER)
-  for (int i = 0; i < W; ++i) v[i] = ok ? 1.f : 0.f;
+  for (int i = 0; i < W; ++i) v[i] = off != WG_OOR ? 1.f : 0.f;
   return;
 #endif
+  // (element access by .x/.y: __builtin_bit_cast(float, t[i]) on a vector element compiles to a b32 load here)
   if constexpr (W == 1) {
-    v[0] = ok ? *p : 0.f;
+    v[0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
   } else if constexpr (W == 2) {
-    const float2 t = ok ? *reinterpret_cast<const float2 *>(p) : make_float2(0.f, 0.f);
-    v[0] = t.x, v[1] = t.y;
+    const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+    v[0] = __uint_as_float(t.x), v[1] = __uint_as_float(t.y);
   } else {
     static_assert(W == 4, "operand vectors are 1, 2 or 4 floats");
-    const float4 t = ok ? *reinterpret_cast<const float4 *>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+    const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+    v[0] = __uint_as_float(t.x), v[1] = __uint_as_float(t.y), v[2] = __uint_as_float(t.z), v[3] = __uint_as_float(t.w);
   }
 }
 template <int AW, int BW>
@@ -340,8 +351,10 @@ struct WgradGroup {  // the operands of 16 pairs
 };
 // pairs [base + 4 q, base + 4 q + 4) of the ring (base a multiple of 16); those at or beyond `end` contribute zeros
 template <int AW, int BW>
-__device__ inline void wgrad_gather(const WgradArgs &a, const int *__restrict__ qi, const int *__restrict__ qo, int base, int end, int q,
-                                    int ca, int cb, bool va, bool vb, WgradGroup<AW, BW> &w) {
+__device__ inline void wgrad_gather(const __amdgpu_buffer_rsrc_t &rsX, const __amdgpu_buffer_rsrc_t &rsZ, const float *__restrict__ xb,
+                                    const float *__restrict__ zb, uint32_t ldx4, uint32_t ldz4,
+                                    const int *__restrict__ qi, const int *__restrict__ qo, int base, int end, int q, uint32_t ca4,
+                                    uint32_t cb4, WgradGroup<AW, BW> &w) {  // ca4 / cb4: byte offset of the lane's channels, WG_OOR if none
   const int p0 = base + 4 * q;
   const int4 iv = *reinterpret_cast<const int4 *>(qi + (p0 & (WG_RING - 1)));
   const int4 ov = *reinterpret_cast<const int4 *>(qo + (p0 & (WG_RING - 1)));
@@ -349,12 +362,16 @@ __device__ inline void wgrad_gather(const WgradArgs &a, const int *__restrict__ 
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     const bool ok = p0 + s < end;
-    wgrad_ldvec<AW>(a.x + (size_t)in[s] * a.ldx + ca, ok && va, w.av[s]);
-    wgrad_ldvec<BW>(a.dz + (size_t)out[s] * a.ldz + cb, ok && vb, w.bv[s]);
+    wgrad_ldvec<AW, AW + BW == 2>(rsX, xb, ok && ca4 != WG_OOR ? (uint32_t)in[s] * ldx4 + ca4 : WG_OOR, w.av[s]);
+    wgrad_ldvec<BW, AW + BW == 2>(rsZ, zb, ok && cb4 != WG_OOR ? (uint32_t)out[s] * ldz4 + cb4 : WG_OOR, w.bv[s]);
   }
 }
 template <int AW, int BW>
 __device__ inline void wgrad_mfma(const WgradGroup<AW, BW> &w, floatx4 (&acc)[AW][BW]) {
+#if defined(SPS_WG_ABLATE_MFMA)
+  for (int s = 0; s < 4; ++s) acc[0][0][s] += w.av[s][0] + w.bv[s][0];
+  return;
+#endif
 #pragma unroll
   for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -377,12 +394,23 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
   const int nchunk = (int)gridDim.x * WG_WAVES;
   const int chunk = blockIdx.x * WG_WAVES + wave;
   const int per = (ngroups + nchunk - 1) / nchunk;
+#if defined(SPS_WG_ABLATE_LOOP)
+  const int g0 = chunk * per, g1 = g0;
+#else
   const int g0 = chunk * per, g1 = min(ngroups, g0 + per);
+#endif
   const int ca0 = ab * 16 * AW, cb0 = bb * 16 * BW;
   const int ca = ca0 + AW * m, cb = cb0 + BW * m;
-  const bool va = ca < a.cin, vb = cb < a.cout;  // channel counts are multiples of 8: a vector is inside or outside as a whole
+  // channel counts are multiples of 8: a vector is inside or outside as a whole
+  const uint32_t ca4 = ca < a.cin ? (uint32_t)ca * 4u : WG_OOR, cb4 = cb < a.cout ? (uint32_t)cb * 4u : WG_OOR;
+  const uint32_t ldx4 = (uint32_t)a.ldx * 4u, ldz4 = (uint32_t)a.ldz * 4u;
   int *__restrict__ qi = q_in[wave], *__restrict__ qo = q_out[wave];
-  const int *__restrict__ tab = a.nbr ? a.nbr + (size_t)k * a.ldn : nullptr;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void *)a.x, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsZ = __builtin_amdgcn_make_buffer_rsrc((void *)a.dz, 0, (int)a.dz_bytes, 0x00020000);
+  // the map's plane of offset k (identity maps: any valid address, never read)
+  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc(
+      (void *)(a.nbr ? a.nbr + (size_t)k * a.ldn : (const int *)a.x), 0, a.nbr ? (int)(a.ldn * 4) : 0, 0x00020000);
+  const bool has_tab = a.nbr != nullptr;
   floatx4 acc[AW][BW];
 #pragma unroll
   for (int i = 0; i < AW; ++i)
@@ -408,11 +436,31 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
   };
   auto entry = [&](int g) -> int {  // the neighbour of row (g << gshift) + lane at offset k (or -1)
     const int row = (g << gshift) + lane;
-    if (g >= g1 || lane >= grows || row >= n) return -1;
-    if (a.tmask && !((tm >> ((row >> 4) - tbase)) & 1ull)) return -1;
-    return tab ? tab[row] : row;
+    bool ok = g < g1 && lane < grows && row < n;
+    if (a.tmask) ok = ok && ((tm >> (((row >> 4) - tbase) & 63)) & 1ull);
+    if (!has_tab) return ok ? row : -1;
+    const int e = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, ok ? (uint32_t)row * 4u : WG_OOR, 0, 0);
+    return ok ? e : -1;
   };
   int qh = 0, qt = 0;  // ring head / tail (wave-uniform, monotonic; position = index mod WG_RING)
+  // Two groups of 16 pairs alternate: the operand rows of one are in flight while the MFMAs of the other issue (gather A,
+  // multiply B, gather B, multiply A).  B stays pending across the steps of the scan.
+  // (1 x 1 blocks -- 8 or 16 channels a side, half the lanes without an operand when 8 -- keep rounds 2-3's form: both
+  // groups gathered with per-lane conditional loads, then multiplied.  Measured at config 2, level-0 8 -> 8 layer: 50-53 us
+  // against 63-66 us with raw buffer loads in either order and 57 us with unconditional loads from a clamped address.)
+  constexpr int NG = 1, UNIT = 16 * NG;
+  constexpr bool PIPE = AW + BW > 2;
+  static_assert(2 * UNIT - 1 + 64 <= WG_RING, "the ring holds the pairs left over plus 64 new ones");
+  WgradGroup<AW, BW> A[NG], B[NG];
+  bool haveB = false;
+  auto gather = [&](WgradGroup<AW, BW> (&U)[NG], int base) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) wgrad_gather<AW, BW>(rsX, rsZ, a.x, a.dz, ldx4, ldz4, qi, qo, base + 16 * i, qt, q, ca4, cb4, U[i]);
+  };
+  auto multiply = [&](const WgradGroup<AW, BW> (&U)[NG]) {
+#pragma unroll
+    for (int i = 0; i < NG; ++i) wgrad_mfma<AW, BW>(U[i], acc);
+  };
   int e_next[WG_UNROLL];
   cover(g0);
 #pragma unroll
@@ -438,40 +486,33 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
       }
       qt += __popcll(bm);
       __builtin_amdgcn_wave_barrier();
-      if constexpr (AW * BW >= 8) {  // (two groups of a 2 x 4 block in flight: 184 bytes of scratch per lane)
-        while (qt - qh >= 16) {
-          WgradGroup<AW, BW> u;
-          wgrad_gather<AW, BW>(a, qi, qo, qh, qt, q, ca, cb, va, vb, u);
-          wgrad_mfma<AW, BW>(u, acc);
-          qh += 16;
+      while (qt - qh >= 2 * UNIT) {
+        if constexpr (PIPE) {
+          gather(A, qh);
+          if (haveB) multiply(B);
+          gather(B, qh + UNIT);
+          multiply(A);
+          haveB = true;
+        } else {
+          gather(A, qh);
+          gather(B, qh + UNIT);
+          multiply(A);
+          multiply(B);
         }
-      } else {
-        while (qt - qh >= 32) {
-          WgradGroup<AW, BW> u, v;
-          wgrad_gather<AW, BW>(a, qi, qo, qh, qt, q, ca, cb, va, vb, u);
-          wgrad_gather<AW, BW>(a, qi, qo, qh + 16, qt, q, ca, cb, va, vb, v);
-          wgrad_mfma<AW, BW>(u, acc);
-          wgrad_mfma<AW, BW>(v, acc);
-          qh += 32;
-        }
+        qh += 2 * UNIT;
       }
       __builtin_amdgcn_wave_barrier();
     }
-    // the next entries are "used" here, where a wait for the gathers above has covered them anyway: the compiler then
-    // knows they are resident at the top of the next iteration instead of draining the queue (vmcnt(0)) right after
-    // requesting the entries after them
-#pragma unroll
-    for (int j = 0; j < WG_UNROLL; ++j) asm volatile("" : "+v"(e_next[j]));
   }
-  if (qt > qh) {  // the chunk's last <= 31 (15) pairs
-    WgradGroup<AW, BW> u;
-    wgrad_gather<AW, BW>(a, qi, qo, qh, qt, q, ca, cb, va, vb, u);
-    wgrad_mfma<AW, BW>(u, acc);
-    if (AW * BW < 8 && qt - qh > 16) {
-      wgrad_gather<AW, BW>(a, qi, qo, qh + 16, qt, q, ca, cb, va, vb, u);
-      wgrad_mfma<AW, BW>(u, acc);
-    }
+  // the chunk's last < 2 UNIT pairs (pairs at or beyond qt read zeros), and the pending unit
+  if (qt > qh) {
+    gather(A, qh);
+    if (haveB) multiply(B);
+    haveB = qt - qh > UNIT;
+    if (haveB) gather(B, qh + UNIT);
+    multiply(A);
   }
+  if (haveB) multiply(B);
   // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i.  The block's tiles go through LDS one after the other.
   float *__restrict__ dst = a.out + ((size_t)blockIdx.x * a.K + k) * (size_t)(a.cin * a.cout);
 #pragma unroll
