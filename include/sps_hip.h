@@ -285,6 +285,18 @@ int sps_train_generation(sps_ctx *ctx, int64_t *generation);
 int sps_train_backward_at(sps_ctx *ctx, int64_t generation, const float *dscores_dev, const float *scores_dev,
                           float *grad_dev, int64_t numel, void *stream);
 
+/* The loss of common_step (reference src/sps/models/models.py:62-72): nn.MSELoss between the scores and the labels of the
+ * rows whose time index is 1 (the scan; the reference selects them with np.where on the host), and the R2Score the same
+ * step logs.  sps_scan_mse: scores_dev [n]; labels_dev / t_dev point at the label / time column of the batch rows (row
+ * strides ld_labels / ld_t in floats); work_dev [4 * 257] doubles (scratch the backward reads: work[0] = the number of
+ * selected rows); out_dev [2] floats = loss, R2.  sps_scan_mse_backward: dscores_dev [n] = gloss * d loss / d scores
+ * (gloss_dev: one float on the device).  f64 sums in a fixed order; stream-ordered, no host synchronisation; no context
+ * (the caller has made the device current). */
+int sps_scan_mse(const float *scores_dev, const float *labels_dev, int64_t ld_labels, const float *t_dev, int64_t ld_t, int64_t n,
+                 double *work_dev, float *out_dev, void *stream);
+int sps_scan_mse_backward(const float *scores_dev, const float *labels_dev, int64_t ld_labels, const float *t_dev, int64_t ld_t,
+                          int64_t n, const double *work_dev, const float *gloss_dev, float *dscores_dev, void *stream);
+
 /* ---- per-stage timing (hipEvents on the caller's stream; for bench.py / DESIGN.md) ------
  * With profiling on, sps_forward records one event after every stage ("reset", "voxelize",
  * "pyramid", "maps", one per convolution by state_dict name, "slice_sigmoid").  After a forward,

@@ -82,6 +82,8 @@ def _load() -> C.CDLL:
         "sps_train_backward": (i32, [vp, vp, vp, vp, i64, vp]),
         "sps_train_generation": (i32, [vp, C.POINTER(i64)]),
         "sps_train_backward_at": (i32, [vp, i64, vp, vp, vp, i64, vp]),
+        "sps_scan_mse": (i32, [vp, vp, i64, vp, i64, i64, vp, vp, vp]),
+        "sps_scan_mse_backward": (i32, [vp, vp, i64, vp, i64, i64, vp, vp, vp, vp]),
         "sps_radius_grid_upload": (i32, [vp, vp, vp, vp, vp, i64, i64, C.c_double, C.c_double, vp]),
         "sps_radius_count": (i32, [vp, vp, i64, i64, vp, vp]),
         "sps_radius_fill": (i32, [vp, vp, i64, i64, vp, vp, vp]),
@@ -118,7 +120,7 @@ EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy",
            "sps_forward_head", "sps_check", "sps_metrics", "sps_metrics_dev",
            "sps_profile_enable", "sps_profile_count", "sps_profile_read", "sps_profile_kernel", "sps_map_upload", "sps_map_upload_voxels",
            "sps_submap_voxel", "sps_submap_voxel_ijk", "sps_transform_points", "sps_filter_prepare", "sps_forward_n",
-           "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_train_generation", "sps_train_backward_at", "sps_radius_grid_upload", "sps_radius_count",
+           "sps_compact_stable", "sps_train_forward", "sps_train_backward", "sps_train_generation", "sps_train_backward_at", "sps_scan_mse", "sps_scan_mse_backward", "sps_radius_grid_upload", "sps_radius_count",
            "sps_radius_fill", "sps_radius_grid_attach", "sps_radius_item", "sps_forward_metrics_n", "sps_level_counts", "sps_get_voxels",
            "sps_get_inverse", "sps_get_parent", "sps_get_map_pairs", "sps_get_tile_masks", "sps_get_nbr", "sps_get_kernel_map", "sps_get_logits", "sps_get_feature"]
 

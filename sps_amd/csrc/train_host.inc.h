@@ -49,7 +49,7 @@ struct sps_train {
   float *gpool = nullptr;                  // gradients of the feature buffers (one allocation, zeroed per backward)
   size_t gpool_bytes = 0;
   float *r_p[9] = {}, *r_g[9] = {};        // BN'd 1x1 downsample branch (the residual operand) of block i (2..8)
-  float *dz = nullptr;                     // scratch: gradient wrt a raw conv output [cap, 64]
+  float *dz = nullptr, *dz2 = nullptr;     // scratch: gradient wrt a raw conv output [cap, 64] (dz2: the second BN of a paired launch)
   float *slab = nullptr;                   // workgroup partials of the weight gradients, every layer its own region
   size_t slab_floats = 0;
   std::vector<WgPlan> wg;                  // per conv: geometry of its k_wgrad launch
@@ -100,6 +100,7 @@ std::vector<FeatDesc> feat_list(sps_ctx *c) {
 }
 
 std::vector<TOp> train_ops(sps_ctx *c);
+inline bool is_downsample(const TOp &op) { return std::strstr(op.name, "downsample") != nullptr; }
 
 int train_reserve(sps_ctx *c) {
   if (!c->train) c->train = new sps_train();
@@ -158,6 +159,7 @@ int train_reserve(sps_ctx *c) {
     TALLOC(t->r_p[b], float, (size_t)cap * rcols[b]);
   }
   TALLOC(t->dz, float, (size_t)cap * 64);
+  TALLOC(t->dz2, float, (size_t)cap * 64);
   // weight gradients: a wave owns aw x bw tiles of 16 x 16 of dW[k] and one chunk of the level's row tiles; the rows are cut
   // into nwg x 16 chunks so that ~16 k waves exist whatever the layer's K x block count (every wave walks its chunk as a
   // chain of dependent loads: short chunks also bound the launch's duration), with at least ~128 rows per chunk at the row
@@ -197,7 +199,7 @@ int train_reserve(sps_ctx *c) {
     TALLOC(t->slab, float, t->slab_floats);
   }
   TALLOC(t->bn_part, double, (size_t)s.bns.size() * BN_WG * 2 * BN_MAXC);
-  TALLOC(t->bn_bpart, double, (size_t)BN_WG * 2 * BN_MAXC);
+  TALLOC(t->bn_bpart, double, (size_t)2 * BN_WG * 2 * BN_MAXC);
   TALLOC(t->fin_part, double, (size_t)BN_WG * 9);
   for (const BnSpec &b : s.bns)
     if (b.c < 8 || b.c > BN_MAXC || (b.c & (b.c - 1)))
@@ -492,33 +494,53 @@ int sps_train_forward(sps_ctx *c, const float *params_dev, int64_t numel, const 
   // operands of this step's weights
   hipLaunchKernelGGL(k_permute_weights, dim3((unsigned)t->perm_blocks), dim3(256), 0, st, t->perm, t->n_perm, t->blob, t->wu, t->wut);
   const auto ops = train_ops(c);
-  for (const TOp &op : ops) {
-    const int ci = s.find_conv(op.name);
-    const ConvSpec &cs = s.convs[ci];
-    const int bi = s.find_bn(cs.bn);
-    const BnSpec &bn = s.bns[bi];
-    const int lo = op.out.level;
-    float *z = t->z[ci];
-    if (op.kind == T_CONV0) {
-      const int g0 = grid_for(c->cap, 64, 4096);
-      hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)g0), dim3(256), 0, st, c->counts + 0, c->lv[0].view(),
-                         t->blob + cs.w_off, t->ones, t->zeros, 0.5f, z, 8, 0, TileOrderArgs{}, g0);
-    } else if (op.kind == T_UP) {
-      rc = conv_plain(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
-    } else {
-      rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
+  // conv1 and the 1x1 downsample of a residual block (consecutive in the list) read the same input: both convolutions are
+  // launched, then ONE statistics and ONE apply launch normalise both outputs (blockIdx.y)
+  for (size_t oi = 0; oi < ops.size();) {
+    const size_t npair = (oi + 1 < ops.size() && is_downsample(ops[oi + 1])) ? 2 : 1;
+    BnFwd2 jobs{};
+    int64_t apply_items = 0;
+    for (size_t j = 0; j < npair; ++j) {
+      const TOp &op = ops[oi + j];
+      const int ci = s.find_conv(op.name);
+      const ConvSpec &cs = s.convs[ci];
+      const int bi = s.find_bn(cs.bn);
+      const BnSpec &bn = s.bns[bi];
+      const int lo = op.out.level;
+      float *z = t->z[ci];
+      if (op.kind == T_CONV0) {
+        const int g0 = grid_for(c->cap, 64, 4096);
+        hipLaunchKernelGGL(k_conv0_fused, dim3((unsigned)g0), dim3(256), 0, st, c->counts + 0, c->lv[0].view(),
+                           t->blob + cs.w_off, t->ones, t->zeros, 0.5f, z, 8, 0, TileOrderArgs{}, g0);
+      } else if (op.kind == T_UP) {
+        rc = conv_plain(c, st, T_UP, lo + 1, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
+      } else {
+        rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cin, cs.cout, t->wu + t->wu_off[ci], op.in.p, op.in.ld, z, cs.cout, false);
+      }
+      if (rc != SPS_OK) return rc;
+      if (!vec4_ok(z, cs.cout) || !vec4_ok(op.out.p, op.out.ld) || (op.res.p && !vec4_ok(op.res.p, op.res.ld)))
+        return fail(SPS_ERR_INVALID, "training BatchNorm operands must be 16-byte aligned (%s)", op.name);
+      BnFwd &b = jobs.j[j];
+      b.Z = z;
+      b.ldz = cs.cout;
+      b.Y = op.out.p;
+      b.ldy = op.out.ld;
+      b.res = op.res.p;
+      b.ldr = op.res.ld;
+      b.gamma = t->blob + bn.off;
+      b.beta = b.gamma + bn.c;
+      b.part = t->bn_part + (size_t)bi * BN_WG * 2 * BN_MAXC;
+      b.fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
+      b.batch_stats = t->batch_stats + cs.ss_off / 2 * 3;
+      b.n_rows = c->counts + lo;
+      b.C = cs.cout;
+      b.relu = op.relu;
+      apply_items = std::max<int64_t>(apply_items, (c->cap >> lo) * (cs.cout / 4));
     }
-    if (rc != SPS_OK) return rc;
-    double *part = t->bn_part + (size_t)bi * BN_WG * 2 * BN_MAXC;
-    float *fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
-    if (!vec4_ok(z, cs.cout) || !vec4_ok(op.out.p, op.out.ld) || (op.res.p && !vec4_ok(op.res.p, op.res.ld)))
-      return fail(SPS_ERR_INVALID, "training BatchNorm operands must be 16-byte aligned (%s)", op.name);
-    hipLaunchKernelGGL(k_bn_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, z, cs.cout, c->counts + lo, cs.cout, part);
-    const float *gamma = t->blob + bn.off, *beta = gamma + bn.c;
+    hipLaunchKernelGGL(k_bn_stats, dim3(BN_WG, (unsigned)npair), dim3(BN_TPB), 0, st, jobs);
     // (every workgroup combines the partials itself: no finish launch in between)
-    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 1024)), dim3(256), 0, st, z, cs.cout,
-                       c->counts + lo, cs.cout, part, fin, t->batch_stats + cs.ss_off / 2 * 3, gamma, beta, op.res.p, op.res.ld,
-                       op.relu, op.out.p, op.out.ld);
+    hipLaunchKernelGGL(k_bn_apply, dim3((unsigned)grid_for(apply_items, 256, 1024), (unsigned)npair), dim3(256), 0, st, jobs);
+    oi += npair;
   }
   // final 1x1 conv + bias, slice, sigmoid (models.py:28-29)
   const ConvSpec &fs = s.convs[s.find_conv("final")];
@@ -599,52 +621,105 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
                      b8o.ld, t->fin_part);
   hipLaunchKernelGGL(k_final_bwd_reduce, dim3(1), dim3(64), 0, st, t->fin_part, t->grad + fs.w_off, t->grad + s.bias_off);
   const auto ops = train_ops(c);
-  for (int oi = (int)ops.size() - 1; oi >= 0; --oi) {
-    const TOp &op = ops[oi];
-    const int ci = s.find_conv(op.name);
-    const ConvSpec &cs = s.convs[ci];
-    const int bi = s.find_bn(cs.bn);
-    const BnSpec &bn = s.bns[bi];
-    const int lo = op.out.level;
-    const float *z = t->z[ci];
-    const float *fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
-    if (!vec4_ok(op.out.g, op.out.ld) || (op.res.g && !vec4_ok(op.res.g, op.res.ld)))
-      return fail(SPS_ERR_INVALID, "training BatchNorm gradients must be 16-byte aligned (%s)", op.name);
-    // BN (+ ReLU, + residual) backward: dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
-    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG), dim3(BN_TPB), 0, st, op.out.g, op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout,
-                       c->counts + lo, cs.cout, fin, t->bn_bpart);
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for((c->cap >> lo) * (cs.cout / 4), 256, 1024)), dim3(256), 0, st, op.out.g,
-                       op.out.ld, op.out.p, op.out.ld, op.relu, z, cs.cout, c->counts + lo, cs.cout, fin, t->bn_bpart,
-                       t->blob + bn.off, t->grad + bn.off, t->grad + bn.off + bn.c, t->dz, cs.cout, op.res.g, op.res.ld);
-    int rc = SPS_OK;
-    if (op.kind == T_CONV0) {
-      hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), t->dz, 8, 0.5f, t->c0part);
-      hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(125), dim3(256), 0, st, t->c0part, C0_WG, t->grad + cs.w_off);
-      continue;  // the input feature is a constant: no data gradient
+  // reverse order; the downsample / conv1 pair of a block shares its two BN launches (their gradients are both complete
+  // once conv2's have been propagated), then each runs its weight and data gradient (downsample first, as before)
+  for (int oi = (int)ops.size() - 1; oi >= 0;) {
+    const int npair = (is_downsample(ops[oi]) && oi >= 1) ? 2 : 1;
+    BnBwd2 jobs{};
+    int64_t apply_items = 0;
+    float *dzs[2] = {t->dz, t->dz2};
+    for (int j = 0; j < npair; ++j) {
+      const TOp &op = ops[oi - j];
+      const int ci = s.find_conv(op.name);
+      const ConvSpec &cs = s.convs[ci];
+      const int bi = s.find_bn(cs.bn);
+      const BnSpec &bn = s.bns[bi];
+      const int lo = op.out.level;
+      if (!vec4_ok(op.out.g, op.out.ld) || (op.res.g && !vec4_ok(op.res.g, op.res.ld)))
+        return fail(SPS_ERR_INVALID, "training BatchNorm gradients must be 16-byte aligned (%s)", op.name);
+      // BN (+ ReLU, + residual) backward: dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
+      BnBwd &b = jobs.j[j];
+      b.dY = op.out.g;
+      b.ldg = op.out.ld;
+      b.Y = op.out.p;
+      b.ldy = op.out.ld;
+      b.Z = t->z[ci];
+      b.ldz = cs.cout;
+      b.fin = t->bn_fin + (size_t)bi * 2 * BN_MAXC;
+      b.gamma = t->blob + bn.off;
+      b.bpart = t->bn_bpart + (size_t)j * BN_WG * 2 * BN_MAXC;
+      b.dgamma = t->grad + bn.off;
+      b.dbeta = t->grad + bn.off + bn.c;
+      b.dZ = dzs[j];
+      b.lddz = cs.cout;
+      b.dres = op.res.g;
+      b.lddr = op.res.ld;
+      b.n_rows = c->counts + lo;
+      b.C = cs.cout;
+      b.relu = op.relu;
+      apply_items = std::max<int64_t>(apply_items, (c->cap >> lo) * (cs.cout / 4));
     }
-    // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated
-    if (op.kind == T_UP) {
-      rc = wgrad_launch(c, st, T_UP, ci, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
+    hipLaunchKernelGGL(k_bn_bwd_stats, dim3(BN_WG, (unsigned)npair), dim3(BN_TPB), 0, st, jobs);
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)grid_for(apply_items, 256, 1024), (unsigned)npair), dim3(256), 0, st, jobs);
+    for (int j = 0; j < npair; ++j) {
+      const TOp &op = ops[oi - j];
+      const int ci = s.find_conv(op.name);
+      const ConvSpec &cs = s.convs[ci];
+      const int lo = op.out.level;
+      const float *dz = dzs[j];
+      int rc = SPS_OK;
+      if (op.kind == T_CONV0) {
+        hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), dz, 8, 0.5f, t->c0part);
+        hipLaunchKernelGGL(k_conv0_wgrad_reduce, dim3(125), dim3(256), 0, st, t->c0part, C0_WG, t->grad + cs.w_off);
+        continue;  // the input feature is a constant: no data gradient
+      }
+      // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated
+      if (op.kind == T_UP) {
+        rc = wgrad_launch(c, st, T_UP, ci, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
+        if (rc != SPS_OK) return rc;
+        // y[child] = x[parent] W[oct]  =>  dx[parent] += sum over children dy[child] W[oct]^T : a gather over the `down` table
+        rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dz, cs.cout, op.in.g, op.in.ld, true);
+      } else if (op.kind == T_DOWN) {
+        rc = wgrad_launch(c, st, T_DOWN, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
+        if (rc != SPS_OK) return rc;
+        // z[parent] = sum over children x[child] W[oct]  =>  dx[child] += dz[parent] W[oct]^T : parent-stationary scatter
+        rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dz, cs.cout, op.in.g, op.in.ld, true);
+      } else {
+        rc = wgrad_launch(c, st, op.kind, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
+        if (rc != SPS_OK) return rc;
+        rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dz, cs.cout, op.in.g, op.in.ld, true);
+      }
       if (rc != SPS_OK) return rc;
-      // y[child] = x[parent] W[oct]  =>  dx[parent] += sum over children dy[child] W[oct]^T : a gather over the `down` table
-      rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
-    } else if (op.kind == T_DOWN) {
-      rc = wgrad_launch(c, st, T_DOWN, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
-      if (rc != SPS_OK) return rc;
-      // z[parent] = sum over children x[child] W[oct]  =>  dx[child] += dz[parent] W[oct]^T : parent-stationary scatter
-      rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
-    } else {
-      rc = wgrad_launch(c, st, op.kind, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, t->dz, cs.cout, t->grad + cs.w_off);
-      if (rc != SPS_OK) return rc;
-      rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], t->dz, cs.cout, op.in.g, op.in.ld, true);
     }
-    if (rc != SPS_OK) return rc;
+    oi -= npair;
   }
   {
     const int rc = wgrad_reduce_all(c, st);
     if (rc != SPS_OK) return rc;
   }
   HIP_TRY(hipMemcpyAsync(grad_dev, t->grad, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, st));
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_scan_mse(const float *scores_dev, const float *labels_dev, int64_t ld_labels, const float *t_dev, int64_t ld_t, int64_t n,
+                 double *work_dev, float *out_dev, void *stream) {
+  if (!scores_dev || !labels_dev || !t_dev || !work_dev || !out_dev || n < 0 || n > SPS_MAX_POINTS)
+    return fail(SPS_ERR_INVALID, "sps_scan_mse: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mse_partial, dim3(MSE_WG), dim3(256), 0, st, scores_dev, labels_dev, ld_labels, t_dev, ld_t, (int)n, work_dev);
+  hipLaunchKernelGGL(k_mse_finish, dim3(1), dim3(64), 0, st, work_dev, out_dev);
+  HIP_TRY(hipGetLastError());
+  return SPS_OK;
+}
+
+int sps_scan_mse_backward(const float *scores_dev, const float *labels_dev, int64_t ld_labels, const float *t_dev, int64_t ld_t,
+                          int64_t n, const double *work_dev, const float *gloss_dev, float *dscores_dev, void *stream) {
+  if (!scores_dev || !labels_dev || !t_dev || !work_dev || !gloss_dev || !dscores_dev || n < 0 || n > SPS_MAX_POINTS)
+    return fail(SPS_ERR_INVALID, "sps_scan_mse_backward: bad arguments");
+  if (n == 0) return SPS_OK;
+  hipLaunchKernelGGL(k_mse_bwd, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, scores_dev, labels_dev,
+                     ld_labels, t_dev, ld_t, (int)n, work_dev, gloss_dev, dscores_dev);
   HIP_TRY(hipGetLastError());
   return SPS_OK;
 }

@@ -114,12 +114,29 @@ __device__ inline void bn_combine(const double *__restrict__ vp, int nparts, int
     }
 }
 
-// pass 1: per channel sum z and sum z^2 (k_bn_stats); pass 2 (k_bn_apply) turns them into fin[0][c] = mean, fin[1][c] =
-// invstd + the batch statistics the host folds into running_mean / running_var: mean, biased var, unbiased var
-__global__ __launch_bounds__(BN_TPB) void k_bn_stats(const float *__restrict__ Z, int ld, const int *__restrict__ n_rows, int C,
-                                                      double *__restrict__ part /* [BN_WG][2][C] */) {
+// A launch of the BN kernels carries up to two BatchNorms over the same level (blockIdx.y): conv1's and the 1x1
+// downsample's of a residual block read the same block input and are independent of each other, forward and backward, so
+// they share their four launches (14 blocks x 2 launches fewer per direction and step).
+struct BnFwd {  // y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] ) with the batch statistics of z
+  const float *Z;
+  float *Y;
+  const float *res, *gamma, *beta;
+  double *part;        // [BN_WG][2][C]
+  float *fin;          // [2][BN_MAXC]: mean, invstd (kept for the backward)
+  float *batch_stats;  // [3][C]: mean, biased var, unbiased var (what the host folds into the running statistics)
+  const int *n_rows;
+  int ldz, ldy, ldr, C, relu;
+};
+struct BnFwd2 {
+  BnFwd j[2];
+};
+// pass 1: per channel sum z and sum z^2; pass 2 (k_bn_apply) turns them into mean / invstd + the batch statistics
+__global__ __launch_bounds__(BN_TPB) void k_bn_stats(BnFwd2 a) {
   __shared__ double red[2][16][BN_MAXC];
-  const int n = *n_rows;
+  const BnFwd &b = a.j[blockIdx.y];
+  const int C = b.C, ld = b.ldz;
+  const float *__restrict__ Z = b.Z;
+  const int n = *b.n_rows;
   const int W = bn_parts(n);
   if ((int)blockIdx.x >= W) return;
   const int per = (n + W - 1) / W;
@@ -136,33 +153,33 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_stats(const float *__restrict__ Z
       s.b[j] += (double)e[j] * (double)e[j];
     }
   }
-  bn_block_reduce(s, C, red, part);
+  bn_block_reduce(s, C, red, b.part);
 }
-// pass 2: y = [relu]( (z - mean) * invstd * gamma + beta [+ residual] ), one float4 per thread step
-__global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, int ldz, const int *__restrict__ n_rows, int C,
-                                                   const double *__restrict__ part, float *__restrict__ fin /* [2][BN_MAXC] */,
-                                                   float *__restrict__ batch_stats /* [3][C] */, const float *__restrict__ gamma,
-                                                   const float *__restrict__ beta, const float *__restrict__ res, int ldr,
-                                                   int relu, float *__restrict__ Y, int ldy) {
+// pass 2, one float4 per thread step
+__global__ __launch_bounds__(256) void k_bn_apply(BnFwd2 a) {
   __shared__ float sc[BN_MAXC], sh[BN_MAXC];
   __shared__ double red[2][256];
-  const int n = *n_rows;
+  const BnFwd &b = a.j[blockIdx.y];
+  const int C = b.C, ldz = b.ldz, ldy = b.ldy, ldr = b.ldr, relu = b.relu;
+  const float *__restrict__ Z = b.Z, *__restrict__ res = b.res;
+  float *__restrict__ Y = b.Y;
+  const int n = *b.n_rows;
   double s0, s1;
-  bn_combine(part, bn_parts(n), C, red, s0, s1);
+  bn_combine(b.part, bn_parts(n), C, red, s0, s1);
   if (threadIdx.x < (unsigned)C) {
     const int c = threadIdx.x;
     const double m = n > 0 ? s0 / n : 0.0;
     double var = n > 0 ? s1 / n - m * m : 0.0;
     if (var < 0) var = 0;
     const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + 1e-5));
-    sc[c] = invstd * gamma[c];
-    sh[c] = beta[c] - mean * invstd * gamma[c];
+    sc[c] = invstd * b.gamma[c];
+    sh[c] = b.beta[c] - mean * invstd * b.gamma[c];
     if (blockIdx.x == 0) {
-      fin[c] = mean;
-      fin[BN_MAXC + c] = invstd;
-      batch_stats[c] = mean;
-      batch_stats[C + c] = (float)var;
-      batch_stats[2 * C + c] = (float)(n > 1 ? var * ((double)n / (double)(n - 1)) : var);  // what running_var accumulates
+      b.fin[c] = mean;
+      b.fin[BN_MAXC + c] = invstd;
+      b.batch_stats[c] = mean;
+      b.batch_stats[C + c] = (float)var;
+      b.batch_stats[2 * C + c] = (float)(n > 1 ? var * ((double)n / (double)(n - 1)) : var);  // what running_var accumulates
     }
   }
   __syncthreads();
@@ -183,14 +200,24 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float *__restrict__ Z, i
   }
 }
 
+struct BnBwd {  // dY -> dZ, dgamma, dbeta, and dA added to the residual operand's gradient
+  const float *dY, *Y, *Z, *fin, *gamma;
+  double *bpart;  // [BN_WG][2][C]
+  float *dgamma, *dbeta, *dZ, *dres;
+  const int *n_rows;
+  int ldg, ldy, ldz, lddz, lddr, C, relu;
+};
+struct BnBwd2 {
+  BnBwd j[2];
+};
 // backward pass 1: dA = dY * (Y > 0 if relu); per channel sum dA and sum dA * xhat (xhat = (z - mean) * invstd)
-// (k_bn_bwd_stats) -> dbeta, dgamma and mean(dA), mean(dA * xhat) (combined at the top of k_bn_bwd_apply)
-__global__ __launch_bounds__(BN_TPB) void k_bn_bwd_stats(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
-                                                          int relu, const float *__restrict__ Z, int ldz,
-                                                          const int *__restrict__ n_rows, int C, const float *__restrict__ fin,
-                                                          double *__restrict__ bpart /* [BN_WG][2][C] */) {
+// -> dbeta, dgamma and mean(dA), mean(dA * xhat) (combined at the top of k_bn_bwd_apply)
+__global__ __launch_bounds__(BN_TPB) void k_bn_bwd_stats(BnBwd2 a) {
   __shared__ double red[2][16][BN_MAXC];
-  const int n = *n_rows;
+  const BnBwd &b = a.j[blockIdx.y];
+  const int C = b.C, ldg = b.ldg, ldy = b.ldy, ldz = b.ldz, relu = b.relu;
+  const float *__restrict__ dY = b.dY, *__restrict__ Y = b.Y, *__restrict__ Z = b.Z, *__restrict__ fin = b.fin;
+  const int n = *b.n_rows;
   const int W = bn_parts(n);
   if ((int)blockIdx.x >= W) return;
   const int per = (n + W - 1) / W;
@@ -223,31 +250,30 @@ __global__ __launch_bounds__(BN_TPB) void k_bn_bwd_stats(const float *__restrict
       s.b[j] += (double)g[j] * (double)xh;
     }
   }
-  bn_block_reduce(s, C, red, bpart);
+  bn_block_reduce(s, C, red, b.bpart);
 }
 // backward pass 2: dZ = gamma * invstd * (dA - mean(dA) - xhat * mean(dA * xhat));
 // the masked gradient dA is also ADDED to dres (the gradient of the residual operand), when given.
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(const float *__restrict__ dY, int ldg, const float *__restrict__ Y, int ldy,
-                                                       int relu, const float *__restrict__ Z, int ldz,
-                                                       const int *__restrict__ n_rows, int C, const float *__restrict__ fin,
-                                                       const double *__restrict__ bpart, const float *__restrict__ gamma,
-                                                       float *__restrict__ dgamma, float *__restrict__ dbeta,
-                                                       float *__restrict__ dZ, int lddz, float *__restrict__ dres, int lddr) {
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(BnBwd2 a) {
   __shared__ float mean_s[BN_MAXC], inv_s[BN_MAXC], k1_s[BN_MAXC], k2_s[BN_MAXC], gi_s[BN_MAXC];
   __shared__ double red[2][256];
-  const int n = *n_rows;
+  const BnBwd &b = a.j[blockIdx.y];
+  const int C = b.C, ldg = b.ldg, ldy = b.ldy, ldz = b.ldz, lddz = b.lddz, lddr = b.lddr, relu = b.relu;
+  const float *__restrict__ dY = b.dY, *__restrict__ Y = b.Y, *__restrict__ Z = b.Z, *__restrict__ fin = b.fin;
+  float *__restrict__ dZ = b.dZ, *__restrict__ dres = b.dres;
+  const int n = *b.n_rows;
   double s0, s1;
-  bn_combine(bpart, bn_parts(n), C, red, s0, s1);
+  bn_combine(b.bpart, bn_parts(n), C, red, s0, s1);
   if (threadIdx.x < (unsigned)C) {
     const int c = threadIdx.x;
     mean_s[c] = fin[c];
     inv_s[c] = fin[BN_MAXC + c];
     k1_s[c] = n > 0 ? (float)(s0 / n) : 0.f;
     k2_s[c] = n > 0 ? (float)(s1 / n) : 0.f;
-    gi_s[c] = gamma[c] * fin[BN_MAXC + c];
+    gi_s[c] = b.gamma[c] * fin[BN_MAXC + c];
     if (blockIdx.x == 0) {
-      dbeta[c] = (float)s0;
-      dgamma[c] = (float)s1;
+      b.dbeta[c] = (float)s0;
+      b.dgamma[c] = (float)s1;
     }
   }
   __syncthreads();
@@ -697,6 +723,65 @@ __global__ __launch_bounds__(256) void k_zero_grads(ZeroArgs z, const int *__res
   float4 *__restrict__ p4 = reinterpret_cast<float4 *>(d.p);  // 16-byte aligned, float counts in multiples of 4 (the host checks)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n >> 2); i += (int64_t)gridDim.x * blockDim.x)
     p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------
+// the loss of common_step (models.py:62-72): nn.MSELoss over the scan's rows (t == 1) + the sums torchmetrics' R2Score needs
+// ------------------------------------------------------------------------------------------
+// work[0..3] = count, sum (s - y)^2, sum y, sum y^2 over the rows with t == 1 (f64, fixed order: per-workgroup partials in
+// work[4 + 4 wg ..], combined in workgroup order); out[0] = loss = work[1] / work[0], out[1] = R2 = 1 - ss_res / ss_tot.
+// (In torch ops this was ~30 launches per step, forward and backward: a tenth of the step's host time.)
+constexpr int MSE_WG = 256;
+__global__ __launch_bounds__(256) void k_mse_partial(const float *__restrict__ scores, const float *__restrict__ labels, int64_t ldl,
+                                                      const float *__restrict__ tcol, int64_t ldt, int n, double *__restrict__ work) {
+  __shared__ double red[4][256];
+  const int per = (n + MSE_WG - 1) / MSE_WG;
+  const int r0 = blockIdx.x * per, r1 = min(n, r0 + per);
+  double s[4] = {0, 0, 0, 0};
+  for (int p = r0 + (int)threadIdx.x; p < r1; p += blockDim.x) {
+    if (tcol[(size_t)p * ldt] != 1.f) continue;
+    const double y = (double)labels[(size_t)p * ldl], d = (double)scores[p] - y;
+    s[0] += 1.0;
+    s[1] += d * d;
+    s[2] += y;
+    s[3] += y * y;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[j][threadIdx.x] = s[j];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) red[j][threadIdx.x] += red[j][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x < 4) work[4 + (size_t)blockIdx.x * 4 + threadIdx.x] = red[threadIdx.x][0];
+}
+__global__ void k_mse_finish(double *__restrict__ work, float *__restrict__ out) {
+  __shared__ double tot[4];
+  const int j = threadIdx.x;
+  if (j < 4) {
+    double s = 0;
+    for (int w = 0; w < MSE_WG; ++w) s += work[4 + (size_t)w * 4 + j];
+    work[j] = s;
+    tot[j] = s;
+  }
+  __syncthreads();
+  if (j == 0) {
+    const double cnt = tot[0], ss_res = tot[1], ss_tot = tot[3] - tot[2] * tot[2] / cnt;
+    out[0] = (float)(ss_res / cnt);  // no selected row: 0 / 0 = NaN, as the mean of an empty tensor
+    out[1] = (float)(1.0 - ss_res / ss_tot);
+  }
+}
+// d loss / d scores[p] = gloss * 2 (s_p - y_p) / count on the selected rows, 0 elsewhere
+__global__ void k_mse_bwd(const float *__restrict__ scores, const float *__restrict__ labels, int64_t ldl, const float *__restrict__ tcol,
+                          int64_t ldt, int n, const double *__restrict__ work, const float *__restrict__ gloss,
+                          float *__restrict__ dscores) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  float g = 0.f;
+  if (tcol[(size_t)p * ldt] == 1.f) g = (float)((double)gloss[0] * 2.0 * ((double)scores[p] - (double)labels[(size_t)p * ldl]) / work[0]);
+  dscores[p] = g;
 }
 
 // nn.BatchNorm1d in training mode refuses a single value per channel (the reference's MinkowskiBatchNorm raises): a level

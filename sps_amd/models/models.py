@@ -218,6 +218,38 @@ class _TrainForward(torch.autograd.Function):
         return (None, None, *out)
 
 
+class _ScanMSE(torch.autograd.Function):
+    """nn.MSELoss over the rows with t == 1 and the R2Score of the same rows (models.py:62-72) in two launches
+    (sps_scan_mse), the gradient wrt the scores in one (sps_scan_mse_backward).  ``batch``: float32 rows (b,x,y,z,t,label)."""
+
+    @staticmethod
+    def forward(fctx, scores, batch):
+        dev = scores.device
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            work = torch.empty(4 * 257, dtype=torch.float64, device=dev)
+            out = torch.empty(2, dtype=torch.float32, device=dev)
+            ld = batch.stride(0)
+            _native.check(_native.lib.sps_scan_mse(scores.data_ptr(), batch.data_ptr() + 20, ld, batch.data_ptr() + 16, ld,
+                                                   scores.shape[0], work.data_ptr(), out.data_ptr(), stream))
+        fctx.save_for_backward(scores, batch, work)
+        loss, r2 = out[0], out[1]
+        fctx.mark_non_differentiable(r2)
+        return loss, r2
+
+    @staticmethod
+    def backward(fctx, gloss, _gr2):
+        scores, batch, work = fctx.saved_tensors
+        with torch.cuda.device(scores.device):
+            stream = torch.cuda.current_stream().cuda_stream
+            g = gloss.to(torch.float32).contiguous()
+            dscores = torch.empty_like(scores)
+            ld = batch.stride(0)
+            _native.check(_native.lib.sps_scan_mse_backward(scores.data_ptr(), batch.data_ptr() + 20, ld, batch.data_ptr() + 16, ld,
+                                                            scores.shape[0], work.data_ptr(), g.data_ptr(), dscores.data_ptr(), stream))
+        return dscores, None
+
+
 class _TrainPlan:
     """What a training step needs from the module, computed once per placement of the module's tensors."""
     __slots__ = ("flat", "checks", "params", "span_of", "n_stats", "run_idx", "stat_idx", "nbt", "perm", "inv_perm")
@@ -368,7 +400,11 @@ class SPSNet(nn.Module):
         gt_labels = batch[:, 5].reshape(-1)
         scores = self.model(coordinates)
         # the reference selects the scan's points (t == 1) with np.where on the host (models.py:65-68): here the same
-        # means are written with a 0/1 weight so that the step never waits for the GPU (no index list, no size to learn)
+        # means are taken over the rows with t == 1 on the device, so the step never waits for the GPU (no index list, no
+        # size to learn) -- in the library's two launches when the batch is a plain float32 matrix on the GPU
+        if (scores.is_cuda and batch.is_cuda and batch.dtype == torch.float32 and batch.dim() == 2 and batch.shape[1] >= 6
+                and batch.stride(1) == 1 and scores.dtype == torch.float32 and scores.is_contiguous()):
+            return _ScanMSE.apply(scores, batch)
         w = (coordinates[:, 4] == 1).to(scores.dtype)
         cnt = w.sum()
         loss = (w * (scores - gt_labels) ** 2).sum() / cnt            # nn.MSELoss over the selected points

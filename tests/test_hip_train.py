@@ -312,3 +312,35 @@ def test_train_mode_batchnorm_refuses_a_single_row():
     with pytest.raises(SpsError) as e:
         cx.check_errors(torch.cuda.current_stream().cuda_stream)
     assert e.value.code == ERR_INVALID and "more than 1 value" in str(e.value)
+
+
+def test_scan_mse_equals_the_torch_formulation_of_common_step():
+    """sps_scan_mse / sps_scan_mse_backward (the loss of common_step in two + one launches) against nn.MSELoss over the
+    rows with t == 1 and torchmetrics' R2Score formula in f64 torch ops -- value, R2 and the gradient wrt the scores;
+    a strided batch view and an all-submap batch (no selected row: NaN like the mean of an empty tensor)."""
+    from sps_amd.models.models import SPSNet, _ScanMSE
+    g = torch.Generator().manual_seed(5)
+    n = 70_001
+    wide = torch.rand((n, 8), generator=g)
+    wide[:, 4] = (torch.rand(n, generator=g) < 0.45).float()
+    wide[:, 5] = torch.rand(n, generator=g)
+    for batch in (wide[:, :6].contiguous().cuda(), wide.cuda()[:, :7]):
+        scores = torch.rand(n, generator=g).cuda().requires_grad_(True)
+        loss, r2 = _ScanMSE.apply(scores, batch)
+        (3.0 * loss).backward()
+        s64 = scores.detach().double().requires_grad_(True)
+        sel = batch[:, 4] == 1
+        y = batch[sel, 5].double()
+        want = torch.mean((s64[sel] - y) ** 2)
+        (3.0 * want).backward()
+        want_r2 = 1.0 - torch.sum((y - s64[sel].detach()) ** 2) / torch.sum((y - y.mean()) ** 2)
+        assert float(loss) == pytest.approx(float(want), rel=1e-6)
+        assert float(r2) == pytest.approx(float(want_r2), rel=1e-6, abs=1e-6)
+        np.testing.assert_allclose(scores.grad.cpu().numpy(), s64.grad.float().cpu().numpy(), rtol=1e-5, atol=1e-12)
+        assert float(scores.grad[~sel].abs().max()) == 0.0
+    none = wide[:, :6].clone()
+    none[:, 4] = 0
+    loss, _ = _ScanMSE.apply(torch.rand(n).cuda(), none.cuda())
+    assert torch.isnan(loss)
+    # and common_step takes this path (same numbers as its torch fallback on a float64 batch view)
+    assert SPSNet.common_step.__code__.co_names.count("_ScanMSE") == 1
