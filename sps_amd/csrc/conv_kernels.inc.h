@@ -527,11 +527,15 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
           const int k = wave * OPW + kk;
           if (!((omask >> k) & 1u)) continue;  // no row of this tile has a child at octant k (wave-uniform)
           int child[4];
+          {
+            const int4 cv4 = *reinterpret_cast<const int4 *>(a.up_down + (size_t)k * a.up_ldn + row0 + q * 4);  // (one load: see k_upconv)
+            const int cv[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int ro = row0 + q * 4 + i;
-            child[i] = ro < count ? a.up_down[(size_t)k * a.up_ldn + ro] : -1;
-            if (child[i] >= a.up_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+            for (int i = 0; i < 4; ++i) {
+              const int ro = row0 + q * 4 + i;
+              child[i] = ro < count ? cv[i] : -1;
+              if (child[i] >= a.up_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+            }
           }
           floatx4 uacc[UNT];
 #pragma unroll
@@ -666,6 +670,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   const bool rmw = !C8 || q < 2;  // C_out <= 8: lane groups 2, 3 hold the zero-padded channels 8..15
   const uint32_t accmul = rmw ? (uint32_t)AST : 0u, accadd = rmw ? 4u * (uint32_t)q : (uint32_t)(64 * AST + 4 * lane);
 
+  // epilogue roles: NW threads per row, CPT consecutive columns each
+  constexpr int EP_TPR = NW, EP_CPT = (C8 ? 8 : 16) / EP_TPR;
+  const int ep_c0 = (int)(threadIdx.x % EP_TPR) * EP_CPT;
+  // (extents unknown here: the row / column tests keep every access inside the arrays; other lanes ask for 0xFFFFFFFF)
+  const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res ? a.res : a.in), 0, (int)0xFFFFFFFEu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsSc = __builtin_amdgcn_make_buffer_rsrc((void *)a.scale, 0, (int)0xFFFFFFFEu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsSh = __builtin_amdgcn_make_buffer_rsrc((void *)a.shift, 0, (int)0xFFFFFFFEu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsFw = __builtin_amdgcn_make_buffer_rsrc((void *)(FIN ? a.fin_w : a.scale), 0, (int)0xFFFFFFFEu, 0x00020000);
+  auto ep_load = [&](const __amdgpu_buffer_rsrc_t &rs, uint32_t off, float (&v)[EP_CPT]) {
+    if constexpr (EP_CPT == 2) {
+      const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0);
+      v[0] = __uint_as_float(t.x), v[1] = __uint_as_float(t.y);
+    } else {
+      static_assert(EP_CPT == 4, "four waves per workgroup: 2 or 4 columns per epilogue thread");
+      const u32x4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+      v[0] = __uint_as_float(t.x), v[1] = __uint_as_float(t.y), v[2] = __uint_as_float(t.z), v[3] = __uint_as_float(t.w);
+    }
+  };
   for (int pos = blockIdx.x; pos < nst; pos += gridDim.x) {
     int4 ent = ent_first;
     if (pos != (int)blockIdx.x) {
@@ -801,17 +823,28 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       }
     }
     PX_STAMP(4);
+    // what the epilogue reads from memory -- residual, BN scale / shift (+ `final` weights) of this thread's columns -- as
+    // branch-free vector loads requested BEFORE the barrier (rounds 2-4: `y = sum * a.scale[col] + a.shift[col]; if (a.res
+    // && ro < count) y += a.res[...]` per column after it: exec-masked blocks with a vmcnt(0) each, up to 2 CPT dependent
+    // round trips at the end of every supertile)
+    const int ep_rr = threadIdx.x / EP_TPR, ep_ro = row0 + ep_rr;
+    float ep_res[EP_CPT], ep_sc[EP_CPT], ep_sh[EP_CPT], ep_fw[EP_CPT];
+    {
+      const bool cin = ep_c0 < a.cout;  // C_out is 8 or 16, c0 a multiple of CPT: the thread's columns are all inside or all outside
+      ep_load(rsR, (a.res && ep_ro < count && cin) ? ((uint32_t)ep_ro * (uint32_t)a.ldr + (uint32_t)ep_c0) * 4u : 0xFFFFFFFFu, ep_res);
+      ep_load(rsSc, cin ? (uint32_t)ep_c0 * 4u : 0xFFFFFFFFu, ep_sc);
+      ep_load(rsSh, cin ? (uint32_t)ep_c0 * 4u : 0xFFFFFFFFu, ep_sh);
+      if constexpr (FIN) ep_load(rsFw, cin ? (uint32_t)ep_c0 * 4u : 0xFFFFFFFFu, ep_fw);
+    }
     __syncthreads();
     PX_STAMP(5);
     // ---- epilogue: the partial sums in wave order, BN scale / shift, residual, ReLU, store (+ `final`)
     {
-      constexpr int TPR = NW;                    // threads per row: NW * 64 threads, 64 rows
-      constexpr int CPT = (C8 ? 8 : 16) / TPR;   // columns per thread
-      const int rr = threadIdx.x / TPR, c0 = (threadIdx.x % TPR) * CPT;
-      const int ro = row0 + rr;
+      const int rr = ep_rr, c0 = ep_c0, ro = ep_ro;
       float fsum = 0.f;
+      float yv[EP_CPT];
 #pragma unroll
-      for (int i = 0; i < CPT; ++i) {
+      for (int i = 0; i < EP_CPT; ++i) {
         const int col = c0 + i;
         float sum = acc_s[0][rr * AST + col];
 #pragma unroll
@@ -819,18 +852,24 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
         const bool cv = col < a.cout;
         float y = 0.f;
         if (cv) {
-          y = sum * a.scale[col] + a.shift[col];
-          if (a.res && ro < count) y += a.res[(size_t)ro * a.ldr + col];
+          y = sum * ep_sc[i] + ep_sh[i];
+          y += ep_res[i];  // (0 without a residual operand)
           if (a.relu) y = fmaxf(y, 0.f);
-          if (ro < count) a.out[(size_t)ro * a.ldo + col] = y;
-          if (FIN) fsum += y * a.fin_w[col];
+          if (FIN) fsum += y * ep_fw[i];
         }
+        yv[i] = y;
         if (UP) acc_s[0][rr * AST + col] = y;  // (this thread alone read the slot: the finished row stays here for the octants)
+      }
+      // C_out is 8 or 16 and c0 a multiple of CPT: the thread's columns are all inside or all outside -- one vector store
+      if (ro < count && c0 < a.cout) {
+        float *__restrict__ op = a.out + (size_t)ro * a.ldo + c0;
+        if constexpr (EP_CPT == 2) *reinterpret_cast<float2 *>(op) = make_float2(yv[0], yv[1]);
+        else *reinterpret_cast<float4 *>(op) = make_float4(yv[0], yv[1], yv[2], yv[3]);
       }
       if (FIN) {
 #pragma unroll
-        for (int o = 1; o < TPR; o <<= 1) fsum += __shfl_xor(fsum, o, 64);
-        if ((threadIdx.x % TPR) == 0 && ro < count) a.fin_out[ro] = fsum + a.fin_b;
+        for (int o = 1; o < EP_TPR; o <<= 1) fsum += __shfl_xor(fsum, o, 64);
+        if ((threadIdx.x % EP_TPR) == 0 && ro < count) a.fin_out[ro] = fsum + a.fin_b;
       }
     }
     if constexpr (UP) {
@@ -852,11 +891,15 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
         for (int t = 0; t < 4; ++t) {
           if (!((om[t] >> k) & 1u)) continue;  // no row of this tile has a child at octant k (wave-uniform)
           int child[4];
+          {
+            const int4 cv4 = *reinterpret_cast<const int4 *>(a.up_down + (size_t)k * a.up_ldn + row0 + 16 * t + q * 4);  // (one load: see k_upconv)
+            const int cv[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int ro = row0 + 16 * t + q * 4 + i;
-            child[i] = ro < count ? a.up_down[(size_t)k * a.up_ldn + ro] : -1;
-            if (child[i] >= a.up_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+            for (int i = 0; i < 4; ++i) {
+              const int ro = row0 + 16 * t + q * 4 + i;
+              child[i] = ro < count ? cv[i] : -1;
+              if (child[i] >= a.up_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+            }
           }
           const floatx4 xa = *reinterpret_cast<const floatx4 *>(acc_s[0] + (16 * t + n) * AST + 4 * q);
           floatx4 d = floatx4{0.f, 0.f, 0.f, 0.f};
@@ -1251,12 +1294,18 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
     for (int kk = 0; kk < 2; ++kk) {
       const int k = 2 * wave + kk;
       if (!((mask >> k) & 1u)) continue;  // no row of this tile has a child at octant k (wave-uniform)
+      // the four children of this lane's rows: ONE 16-byte load (the table holds whole tiles: capacities are multiples of
+      // 16; rows >= count are masked afterwards) instead of four conditional loads with a round trip each
       int child[4];
+      {
+        const int4 cv4 = *reinterpret_cast<const int4 *>(a.nbr + (size_t)k * a.ldn + row0 + q * 4);
+        const int cv[4] = {cv4.x, cv4.y, cv4.z, cv4.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ro = row0 + q * 4 + i;
-        child[i] = ro < count ? a.nbr[(size_t)k * a.ldn + ro] : -1;
-        if (a.out_rows > 0 && child[i] >= a.out_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+        for (int i = 0; i < 4; ++i) {
+          const int ro = row0 + q * 4 + i;
+          child[i] = ro < count ? cv[i] : -1;
+          if (a.out_rows > 0 && child[i] >= a.out_rows) child[i] = -1;  // never scatter outside the fine level's arrays
+        }
       }
       floatx4 acc[NT];
 #pragma unroll

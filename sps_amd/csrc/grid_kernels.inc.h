@@ -15,6 +15,7 @@
 // (c) a neighbour lookup is "adjacent block (precomputed per block) + mask test + popcount": the hash
 // is probed 81 times per block instead of 81..125 times per voxel.
 // ------------------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));  // (what the raw buffer loads return; also in conv_kernels.inc.h)
 constexpr int SCAN_BLOCK = 1024;
 
 struct BHash {
@@ -475,12 +476,25 @@ __device__ inline void link_levels(const PyramidArgs &a, int l, int bx, int nbx)
     a.bchild[l + 1][(size_t)pr * 8 + ((bx & 1) | ((by & 1) << 1) | ((bz & 1) << 2))] = r;
     if (l == 0) {
       const unsigned long long m = a.bmask[0][r];
+      // the four ancestors' (slot -> rank, mask -> row base) chains are independent: all loads of a step are issued before
+      // anything is stored (the arrays are not `restrict`: a store between them makes the compiler finish one ancestor's
+      // three dependent round trips before it requests the next one's)
+      int sj[NLV], brj[NLV], basej[NLV];
+      unsigned long long pmj[NLV];
+#pragma unroll
+      for (int j = 1; j < NLV; ++j) sj[j] = a.sslot[j][r];
 #pragma unroll
       for (int j = 1; j < NLV; ++j) {
-        const int s = a.sslot[j][r];
-        const int br = a.h[j].rank[s];
-        const unsigned long long pmask = a.h[j].mask[s];
-        const int base = a.bbase[j][br];
+        brj[j] = a.h[j].rank[sj[j]];
+        pmj[j] = a.h[j].mask[sj[j]];
+      }
+#pragma unroll
+      for (int j = 1; j < NLV; ++j) basej[j] = a.bbase[j][brj[j]];
+#pragma unroll
+      for (int j = 1; j < NLV; ++j) {
+        const int br = brj[j];
+        const unsigned long long pmask = pmj[j];
+        const int base = basej[j];
         if (j == 1) {
           const uint32_t ox = bx & 1, oy = by & 1, oz = bz & 1;
 #pragma unroll
@@ -547,6 +561,9 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
   const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];  // a time index no block has needs no probe
   const uint64_t *__restrict__ bkey = a.bkey[level];
   int *__restrict__ badj = a.badj[level];
+  const __amdgpu_buffer_rsrc_t rsOcc = __builtin_amdgcn_make_buffer_rsrc((void *)h.occ, 0, (int)0xFFFFFFFEu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsKeys = __builtin_amdgcn_make_buffer_rsrc((void *)h.keys, 0, (int)0xFFFFFFFEu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsRank = __builtin_amdgcn_make_buffer_rsrc((void *)h.rank, 0, (int)0xFFFFFFFEu, 0x00020000);
   for (int i = (bx - lo) * 256 + (int)threadIdx.x; i < total; i += (hi - lo) * 256) {
     const int r = i / 27, g = i - r * 27;
     const int dy = g % 3 - 1, dz = (g / 3) % 3 - 1, dt = g / 9 - 1;
@@ -571,21 +588,31 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
       nk[j] = gkey + (uint64_t)(int64_t)dx;
       sl[j] = (ghash + (uint32_t)dx * BH_X) >> h.hshift;
     }
+    // Raw buffer loads (offset 0xFFFFFFFF: no access, zeros): the three loads of a phase are branch-free and in flight
+    // together.  (`x = probe ? table[slot] : 0` per entry compiled to one exec-masked block + vmcnt(0) per load: the three
+    // phases cost nine dependent round trips.)
     uint32_t ow[LINK_PER];
 #pragma unroll
-    for (int j = 0; j < LINK_PER; ++j) ow[j] = probe[j] ? h.occ[sl[j] >> 5] : 0u;
+    for (int j = 0; j < LINK_PER; ++j) ow[j] = __builtin_amdgcn_raw_buffer_load_b32(rsOcc, probe[j] ? (sl[j] >> 5) * 4u : 0xFFFFFFFFu, 0, 0);
     uint64_t k1[LINK_PER];
 #pragma unroll
     for (int j = 0; j < LINK_PER; ++j) {
       probe[j] = probe[j] && ((ow[j] >> (sl[j] & 31)) & 1u);  // a free first slot: the block does not exist
-      k1[j] = probe[j] ? h.keys[sl[j]] : KEY_EMPTY;
+      const u32x2 kv = __builtin_amdgcn_raw_buffer_load_b64(rsKeys, probe[j] ? sl[j] * 8u : 0xFFFFFFFFu, 0, 0);
+      k1[j] = ((uint64_t)kv.y << 32) | kv.x;
+    }
+    bool hit[LINK_PER];
+    int rk[LINK_PER];
+#pragma unroll
+    for (int j = 0; j < LINK_PER; ++j) {
+      hit[j] = probe[j] && k1[j] == nk[j];
+      rk[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsRank, hit[j] ? sl[j] * 4u : 0xFFFFFFFFu, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < LINK_PER; ++j) {
-      if (!probe[j]) continue;
-      if (k1[j] == nk[j]) {
-        res[j] = h.rank[sl[j]];
-      } else {  // the first slot holds another block: walk on (rare)
+      if (hit[j]) {
+        res[j] = rk[j];
+      } else if (probe[j]) {  // the first slot holds another block: walk on (rare)
         const int s2 = bhash_find_from(h, nk[j], (sl[j] + 1) & h.hmask);
         if (s2 >= 0) res[j] = h.rank[s2];
       }

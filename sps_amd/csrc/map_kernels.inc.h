@@ -6,6 +6,8 @@
 // ------------------------------------------------------------------------------------------
 enum NbrKind { NBR_3333 = 0, NBR_5551 = 1 };
 
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // (what the raw buffer loads return; also in conv_kernels.inc.h)
+
 struct LevelView {
   const int *vblock;
   const unsigned char *vbit;
@@ -121,10 +123,21 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   int *__restrict__ rbc = a.rb_cnt[l];
   const unsigned long long ltm = (1ull << lane) - 1ull;
   const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];
+  // Raw buffer loads (offset 0xFFFFFFFF = no access, zeros) for the per-lane optional fetches below: they are branch-free,
+  // so the 8 adjacency entries are requested together and the 8 (mask, base) records together -- two round trips.  (Round
+  // 2-4's `if (need) nb = adj[e]; if (nb >= 0) q = bmb[nb];` compiled to one exec-masked block per load with a vmcnt(0)
+  // between them: eight dependent round trips per row.)
+  constexpr uint32_t OOR = 0xFFFFFFFFu;
+  const __amdgpu_buffer_rsrc_t rsAdj = __builtin_amdgcn_make_buffer_rsrc((void *)L.badj, 0, (int)0xFFFFFFFEu, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsBmb = __builtin_amdgcn_make_buffer_rsrc((void *)L.bmb, 0, (int)0xFFFFFFFEu, 0x00020000);
   for (int u = local * 256 + (int)threadIdx.x; u < nround; u += nchunks * 256) {
     const bool ok = u < n;
-    const int r = ok ? L.vblock[u] : 0;
-    const int bit = ok ? L.vbit[u] : 0;
+    // (rows [n, nround) exist in the arrays -- capacities are multiples of 1024 -- so both loads are unconditional and
+    // issue together; what they return there is not used)
+    const int r_raw = L.vblock[u];
+    const int bit_raw = L.vbit[u];
+    const int r = ok ? r_raw : 0;
+    const int bit = ok ? bit_raw : 0;
     const int px = bit & 3, py = (bit >> 2) & 3, pz = bit >> 4;
     // time slice dt = slice - 1 of a row at time index t is empty when no block of the forward has index t + dt (a scan +
     // submap batch holds two indices: a third of the (row, slice) walks ends here)
@@ -135,21 +148,25 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       if (rbc && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = 0;
       continue;
     }
-    const int *__restrict__ adj = L.badj + (size_t)r * 81 + slice * 27;
+    const uint32_t adj4 = ((uint32_t)r * 81u + (uint32_t)slice * 27u) * 4u;
     // The 3x3x3 neighbourhood of a voxel touches at most two blocks per axis (its own and, from a face voxel, the one
     // behind that face): the up to 8 blocks (mask, row base) are fetched ONCE -- 3.4 on average, against 18 adjacency + 36
     // mask / base loads when every (dy, dz) run fetched its own -- and every offset selects among them in registers.
     const int sx = px == 0 ? -1 : (px == 3 ? 1 : 0), sy = py == 0 ? -1 : (py == 3 ? 1 : 0), sz = pz == 0 ? -1 : (pz == 3 ? 1 : 0);
     uint32_t mlo[8], mhi[8];
-    int bs[8];
+    int bs[8], nbv[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       const bool need = act && (!(c & 1) || sx != 0) && (!(c & 2) || sy != 0) && (!(c & 4) || sz != 0);
       const int e = (((c & 4) ? sz : 0) + 1) * 9 + (((c & 2) ? sy : 0) + 1) * 3 + (((c & 1) ? sx : 0) + 1);
-      int nb = -1;
-      if (need) nb = (c == 0 && slice == 1) ? r : adj[e];  // (entry 40 of the table is the block itself)
-      uint4 q = make_uint4(0u, 0u, 0u, 0u);
-      if (nb >= 0) q = L.bmb[nb];
+      // (c = 0 in slice 1 is the block itself, entry 40 of its row: read like the others -- a branch around one load
+      // would make the compiler drain the queue before the loads behind it)
+      const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsAdj, need ? adj4 + (uint32_t)e * 4u : OOR, 0, 0);
+      nbv[c] = need ? v : -1;
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsBmb, nbv[c] >= 0 ? (uint32_t)nbv[c] * 16u : OOR, 0, 0);
       mlo[c] = q.x, mhi[c] = q.y, bs[c] = (int)q.z;
     }
     uint32_t m = 0u;
