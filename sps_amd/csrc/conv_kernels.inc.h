@@ -881,7 +881,10 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       const float usc = n < a.up_cout ? a.up_scale[n] : 0.f, ush = n < a.up_cout ? a.up_shift[n] : 0.f;
       uint32_t om[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) om[t] = row0 + 16 * t < count ? a.up_tmask[(size_t)(st * 4 + t) * 4] & 0xFFu : 0u;
+      for (int t = 0; t < 4; ++t) {  // (unconditional loads -- the mask array holds whole supertiles -- then the row test: four
+        const uint32_t w = a.up_tmask[(size_t)(st * 4 + t) * 4];  //  conditional loads were four dependent round trips)
+        om[t] = row0 + 16 * t < count ? w & 0xFFu : 0u;
+      }
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * wave + kk;
@@ -1326,15 +1329,26 @@ __global__ __launch_bounds__(256) void k_upconv(ConvArgs a) {
         }
       }
       // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
+      // accumulate mode (training: data gradient of a stride conv): the four values a column tile adds to are requested
+      // together, branch-free (`if (a.res) y += a.res[...]` per element: NT x 4 dependent round trips per octant; all NT x 4
+      // at once would cost k_upconv<4> 22 VGPRs in the inference launches too)
+      const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc((void *)(a.res ? a.res : a.out), 0, (int)0xFFFFFFFEu, 0x00020000);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const int col = nt * 16 + r;
         if (col >= a.cout) continue;
+        float rv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (a.res) {  // workgroup-uniform
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            rv[i] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                rsR, child[i] >= 0 ? ((uint32_t)child[i] * (uint32_t)a.ldr + (uint32_t)col) * 4u : 0xFFFFFFFFu, 0, 0));
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if (child[i] < 0) continue;
           float y = acc[nt][i] * esc[nt] + esh[nt];
-          if (a.res) y += a.res[(size_t)child[i] * a.ldr + col];  // accumulate (training: data gradient of a stride conv)
+          y += rv[i];
           if (a.relu) y = fmaxf(y, 0.f);
           a.out[(size_t)child[i] * a.ldo + col] = y;
         }
@@ -1376,6 +1390,7 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: wave-uniform tests stay on the SALU)
   const int r = lane & 15, q = lane >> 4;
   const float esc = r < 8 ? scale[r] : 0.f, esh = r < 8 ? shift[r] : 0.f;
+  const __amdgpu_buffer_rsrc_t rsM = __builtin_amdgcn_make_buffer_rsrc((void *)L.bmask, 0, (int)0xFFFFFFFEu, 0x00020000);
   for (int tile = bid * 4 + wave; tile < ntiles; tile += g0 * 4) {
     const int row0 = tile * 16;
     const int u = row0 + r;
@@ -1397,8 +1412,10 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
       const int ysel = q & 1, zsel = q >> 1;
       const int *adj = L.badj + (size_t)blk * 81 + 27 + (lz + zsel + 1) * 9 + (ly + ysel + 1) * 3 + (lx + 1);
       const int nb0 = adj[0], nb1 = adj[1];
-      const unsigned long long M0 = nb0 >= 0 ? L.bmask[nb0] : 0ull, M1 = nb1 >= 0 ? L.bmask[nb1] : 0ull;
-      const uint32_t m0lo = (uint32_t)M0, m0hi = (uint32_t)(M0 >> 32), m1lo = (uint32_t)M1, m1hi = (uint32_t)(M1 >> 32);
+      // (branch-free: both masks in flight together; `nb >= 0 ? L.bmask[nb] : 0` twice was two dependent round trips)
+      const u32x2 M0 = __builtin_amdgcn_raw_buffer_load_b64(rsM, nb0 >= 0 ? (uint32_t)nb0 * 8u : 0xFFFFFFFFu, 0, 0);
+      const u32x2 M1 = __builtin_amdgcn_raw_buffer_load_b64(rsM, nb1 >= 0 ? (uint32_t)nb1 * 8u : 0xFFFFFFFFu, 0, 0);
+      const uint32_t m0lo = M0.x, m0hi = M0.y, m1lo = M1.x, m1hi = M1.y;
       // rows ty of the window inside this group's y block: [ty0, ty1]; the same along z
       const int ysplit = 4 * (ly + 1), zsplit = 4 * (lz + 1);
       const int ty0 = ysel ? ysplit : py - 2, ty1 = ysel ? py + 2 : ysplit - 1;
