@@ -45,7 +45,7 @@ struct ConvArgs {
   // k_conv_ws (coarse levels): slab of the slices' partial sums + one ticket per supertile; workgroups wanted per launch
   // and the largest slice count
   const int4 *px_order;    // k_conv_px: position -> {supertile, chunks of its three slices}, balanced order (px_order_body), or null
-  const int *tile_order;   // k_conv: the level's tiles sorted by present-offset count, heaviest first (k_tile_order), or null
+  const int4 *tile_order;  // k_conv: the level's tiles sorted by present-offset count, heaviest first, {tile, mask words} (tile_order_body), or null
   int order_ways;          // > 0: positions are laid out boustrophedon over tiers of this many (positions that share a CU)
   float *slab;
   int *ticket;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
     const int pos = grp * tpw + tl;
     const bool active = pos < ntiles;
     int tile = pos;
+    int4 oent = make_int4(0, 0, 0, 0);
     if (a.tile_order && active) {
       int idx = pos;
       if (a.order_ways > 0) {  // odd tiers run backwards (a last, partial tier is taken as is)
@@ -182,7 +183,8 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
         const int len = min(a.order_ways, ntiles - tier * a.order_ways);
         idx = tier * a.order_ways + ((tier & 1) ? len - 1 - c : c);
       }
-      tile = a.tile_order[idx];
+      oent = a.tile_order[idx];
+      tile = oent.x;
     }
     if (S == 1 && !active) continue;
     const int row0 = tile * 16;
@@ -193,6 +195,9 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
       uint32_t w0 = pw0, w1 = pw1;
       if (!active) {
         w0 = w1 = 0u;
+      } else if (a.tile_order) {  // the order entry carries the tile's mask words (word 3 is never written)
+        w0 = (lane >> 5) ? (uint32_t)oent.z : (uint32_t)oent.y;
+        w1 = (lane >> 5) ? 0u : (uint32_t)oent.w;
       } else if (tile != tile_first) {
         const uint32_t *m = a.tmask + (size_t)tile * 4;
         w0 = m[lane >> 5];

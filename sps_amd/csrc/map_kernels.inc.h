@@ -407,7 +407,7 @@ __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slic
 //   tile_order_body (one workgroup per level) sorts the tiles of a level by their present-offset count (counting sort, 82
 //   buckets, heaviest first) and lays them out boustrophedon over tiers of TILE_ORDER_WAYS positions, so that the positions
 //   p, p + WAYS, p + 2 WAYS ... that round-robin dispatch gives to one CU hold one heavy, one light, one heavy ... tile.
-//   order[p] = tile of position p; the convolution results do not depend on it (a tile is computed the same wherever it runs).
+//   order[p] = {tile of position p, its mask words}; the convolution results do not depend on it (a tile is computed the same wherever it runs).
 // ------------------------------------------------------------------------------------------
 #ifndef SPS_TILE_ORDER
 #define SPS_TILE_ORDER 2   // 0: natural order (no kernel), 1: heaviest first, 2: heaviest first, k_conv lays the positions out boustrophedon
@@ -419,7 +419,7 @@ constexpr int TILE_ORDER = SPS_TILE_ORDER, TILE_ORDER_WAYS = SPS_TILE_ORDER_WAYS
 constexpr int TILE_ORDER_FIRST_LEVEL = 2;
 struct TileOrderArgs {
   const uint32_t *tm3[NLV];
-  int *order[NLV];
+  int4 *order[NLV];
   const int *counts;
   // pair-exact levels: supertiles by chunk count (k_conv_px reads {supertile, chunks per slice} at its position)
   const int *rb_cnt[NLV];
@@ -468,10 +468,13 @@ __device__ inline void tile_order_body(const TileOrderArgs &a, int which) {
   __syncthreads();
   bucket_starts_desc(hist, start, 82);  // heaviest first
   __syncthreads();
-  int *__restrict__ sorted = a.order[l];
+  // an entry = {tile, its three mask words}: the convolution gets the tile and its present-offset list from ONE load (the
+  // mask words used to be a second, dependent round trip at the start of every tile)
+  int4 *__restrict__ sorted = a.order[l];
   for (int t = threadIdx.x; t < nt; t += blockDim.x) {
-    const int w = __popc(tm[(size_t)t * 4] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 1] & 0x7FFFFFFu) + __popc(tm[(size_t)t * 4 + 2] & 0x7FFFFFFu);
-    sorted[start[w] + atomicAdd(&cursor[w], 1)] = t;  // (the order inside a bucket varies from run to run: scheduling only)
+    const uint4 m = *reinterpret_cast<const uint4 *>(tm + (size_t)t * 4);
+    const int w = __popc(m.x & 0x7FFFFFFu) + __popc(m.y & 0x7FFFFFFu) + __popc(m.z & 0x7FFFFFFu);
+    sorted[start[w] + atomicAdd(&cursor[w], 1)] = make_int4(t, (int)m.x, (int)m.y, (int)m.z);  // (the order inside a bucket varies from run to run: scheduling only)
   }
 }
 

@@ -168,7 +168,7 @@ struct Level {
   int *nbr3 = nullptr;         // [81][cap]
   int *down = nullptr;         // [8][cap]  (levels 1..4) children of each voxel in level-1
   uint32_t *tm3 = nullptr, *tmdown = nullptr;  // [cap/16][4] present-offset masks per 16-row tile
-  int *tile_order = nullptr;  // [cap/16] the level's tiles sorted by present-offset count (conv0 launch; read by k_conv)
+  int4 *tile_order = nullptr;  // [cap/16] the level's tiles sorted by present-offset count, each with its three mask words (conv0 launch; read by k_conv)
   int *px_sorted = nullptr;   // [cap/64] pair-exact levels: supertiles sorted by chunk count
   int4 *px_order = nullptr;   // [cap/64] position -> {supertile, chunks per slice} (conv0 launch; read by k_conv_px)
   // rulebook of the 3x3x3x3 map (levels that run k_conv_px): per supertile of 64 rows
@@ -420,7 +420,7 @@ int reserve(sps_ctx *c, int64_t n) {
         ALLOC(L.down, int, 8 * rows);
       }
       L.tile_order = nullptr;
-      if (TILE_ORDER != 0 && l >= TILE_ORDER_FIRST_LEVEL) ALLOC(L.tile_order, int, rows / 16);
+      if (TILE_ORDER != 0 && l >= TILE_ORDER_FIRST_LEVEL) ALLOC(L.tile_order, int4, rows / 16);
       // never-written entries must still be valid indices (stale reads in an aborted forward stay in range)
       HIP_TRY(hipMemset(L.vblock, 0, sizeof(int) * (size_t)rows));
       HIP_TRY(hipMemset(L.vbit, 0, (size_t)rows));
