@@ -19,11 +19,12 @@ for name, K, cin, cout, lin, lout, kind in R.LAYERS:
     f += 2 * P * cin * cout
     b += 4 * (V[lin] * cin + V[lout] * cout + K * cin * cout) + (8 * P if K > 1 else 0)
     g += 4 * P * (cin + cout)
-t = us(lambda n: "k_wgrad(" in n) * 1e-6
+is_wgrad = lambda n: "k_wgrad<" in n or "k_wgrad(" in n     # (k_wgrad<AW, BW> since round 4; the reduce kernels have other names)
+t = us(is_wgrad) * 1e-6
 tc = us(lambda n: "k_conv<" in n or "k_upconv" in n) * 1e-6
 tb = us(lambda n: "k_bn_" in n)
 print(f"kernel time per training step: {us(lambda n: True):.0f} us in {calls(lambda n: True):.0f} launches")
-print(f"k_wgrad: {t * 1e6:.0f} us in {calls(lambda n: 'k_wgrad(' in n):.0f} launches for {f / 1e9:.2f} GFLOP / {b / 1e6:.0f} MB algorithmic -> "
+print(f"k_wgrad: {t * 1e6:.0f} us in {calls(is_wgrad):.0f} launches for {f / 1e9:.2f} GFLOP / {b / 1e6:.0f} MB algorithmic -> "
       f"{f / t / 1e12:.2f} TFLOP/s = {f / t / 1e12 / R.MFMA_F32_PEAK_TFLOPS:.3f} of the f32-MFMA peak, {b / t / 1e9:.0f} GB/s = "
       f"{b / t / 1e9 / R.HBM_PEAK_GBS:.3f} of the HBM roofline; gathered operand rows {g / 1e9:.2f} GB = {g / t / 1e12:.2f} TB/s through the L1s")
 print(f"forward + data-gradient convolutions (k_conv, k_upconv): {tc * 1e6:.0f} us for 2 x {w['flops'] / 1e9:.2f} GFLOP -> "
