@@ -884,12 +884,14 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
       __syncthreads();
       const __amdgpu_buffer_rsrc_t rsU = __builtin_amdgcn_make_buffer_rsrc((void *)a.up_Wu, 0, (int)a.up_wu_bytes, 0x00020000);
       const float usc = n < a.up_cout ? a.up_scale[n] : 0.f, ush = n < a.up_cout ? a.up_shift[n] : 0.f;
+      const __amdgpu_buffer_rsrc_t rsUm = __builtin_amdgcn_make_buffer_rsrc((void *)a.up_tmask, 0, (int)0xFFFFFFFEu, 0x00020000);
       uint32_t om[4];
+      // ONE load: lane group q fetches the mask of tile q, the four words are then read from lanes 0 / 16 / 32 / 48 (four
+      // conditional loads were four dependent round trips; four wave-uniform loads are too: the compiler moves each through
+      // the same register into an SGPR)
+      const uint32_t omv = __builtin_amdgcn_raw_buffer_load_b32(rsUm, row0 + 16 * q < count ? (uint32_t)(st * 4 + q) * 16u : 0xFFFFFFFFu, 0, 0) & 0xFFu;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {  // (unconditional loads -- the mask array holds whole supertiles -- then the row test: four
-        const uint32_t w = a.up_tmask[(size_t)(st * 4 + t) * 4];  //  conditional loads were four dependent round trips)
-        om[t] = row0 + 16 * t < count ? w & 0xFFu : 0u;
-      }
+      for (int t = 0; t < 4; ++t) om[t] = (uint32_t)__builtin_amdgcn_readlane((int)omv, 16 * t);
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int k = 2 * wave + kk;
