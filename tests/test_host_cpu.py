@@ -304,3 +304,28 @@ def test_scalar_log_writes_lightning_csv_layout(tmp_path):
     assert list(rows[0]) == ["epoch", "step", "train_loss", "train_r2", "lr-Adam", "val_loss", "val_r2"]
     assert [r["train_loss"] for r in rows] == ["0.5", "", "0.125"] and rows[1]["val_loss"] == "0.25" and rows[2]["epoch"] == "1"
     assert log.dir.endswith("version_0") and ScalarLog(str(tmp_path), "BLT").dir.endswith("version_1")
+
+
+@pytest.mark.timeout(600)
+def test_inference_kernels_have_no_serialised_optional_loads():
+    """a per-lane `x = cond ? table[i] : 0` compiles to an exec-masked block per load and a vmcnt(0) after it, so
+    N independent optional loads cost N memory round trips.  tools/isa_single_loads.py lists the loads that sit alone between
+    two vmcnt(0) in the gfx950 ISA; what is left on the inference path are chains that are dependent by nature (hash walks,
+    slot -> rank -> row base, the per-supertile entry of k_conv_px).  Ceilings = the counts of round 4's final build + 2."""
+    import re
+    import shutil
+    import subprocess
+    import sys
+    if not shutil.which("hipcc") and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "isa_single_loads.py"), "k_maps", "k_link_adj", "k_conv_px", "k_conv0_fused",
+                          "k_points_to_blocks"], capture_output=True, text=True, check=True).stdout
+    counts = {m.group(1): int(m.group(2)) for m in re.finditer(r"^(\S[^:]*): (\d+)", out, re.M)}
+    assert counts, out
+    ceilings = {"k_maps": 8, "k_link_adj": 16, "k_conv0_fused": 12, "k_points_to_blocks": 2}
+    for name, n in counts.items():
+        if name.startswith("k_conv_px"):
+            assert n <= 4, (name, n, out)     # the supertile's order / count entry (+ nothing in the epilogues)
+        elif name in ceilings:
+            assert n <= ceilings[name], (name, n, out)
