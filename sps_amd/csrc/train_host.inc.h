@@ -49,7 +49,8 @@ struct sps_train {
   float *gpool = nullptr;                  // gradients of the feature buffers (one allocation, zeroed per backward)
   size_t gpool_bytes = 0;
   float *r_p[9] = {}, *r_g[9] = {};        // BN'd 1x1 downsample branch (the residual operand) of block i (2..8)
-  float *dz = nullptr, *dz2 = nullptr;     // scratch: gradient wrt a raw conv output [cap, 64] (dz2: the second BN of a paired launch)
+  std::vector<float *> dzl;                // per conv: gradient wrt its raw output [cap, cout] (kept until the weight gradients run, at the end)
+  std::vector<WgradJobs> wjobs;            // weight-gradient jobs of the running backward, by block shape (wgrad_shape_index)
   float *slab = nullptr;                   // workgroup partials of the weight gradients, every layer its own region
   size_t slab_floats = 0;
   std::vector<WgPlan> wg;                  // per conv: geometry of its k_wgrad launch
@@ -158,8 +159,11 @@ int train_reserve(sps_ctx *c) {
     gp += (size_t)cap * rcols[b];
     TALLOC(t->r_p[b], float, (size_t)cap * rcols[b]);
   }
-  TALLOC(t->dz, float, (size_t)cap * 64);
-  TALLOC(t->dz2, float, (size_t)cap * 64);
+  t->dzl.assign(s.convs.size(), nullptr);
+  for (size_t i = 0; i < s.convs.size(); ++i) {
+    if (s.convs[i].name == "final") continue;
+    TALLOC(t->dzl[i], float, (size_t)cap * s.convs[i].cout);
+  }
   // weight gradients: a wave owns aw x bw tiles of 16 x 16 of dW[k] and one chunk of the level's row tiles; the rows are cut
   // into nwg x 16 chunks so that ~16 k waves exist whatever the layer's K x block count (every wave walks its chunk as a
   // chain of dependent loads: short chunks also bound the launch's duration), with at least ~128 rows per chunk at the row
@@ -377,13 +381,14 @@ int conv_plain(sps_ctx *c, hipStream_t st, TKind gather, int level_rows, int K, 
   return launch_k_conv(a, g, false, grid, st);
 }
 
-template <int AW, int BW>
-void wgrad_go(const WgradArgs &w, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((k_wgrad<AW, BW>), grid, dim3(WG_WAVES * 64), 0, st, w);
+constexpr int WGRAD_SHAPES = 6;
+inline int wgrad_shape_index(int aw, int bw) {  // <1,1> <1,2> <1,4> <2,1> <2,2> <2,4>
+  return (aw == 2 ? 3 : 0) + (bw == 4 ? 2 : bw == 2 ? 1 : 0);
 }
 
-int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int conv_index, int level_rows, int K, int cin, int cout, const float *x,
-                 int ldx, const float *dz, int ldz, float *dW) {
+// The weight gradient of a layer joins the job table of its block shape; wgrad_run launches the tables at the end of the backward.
+int wgrad_defer(sps_ctx *c, TKind kind, int conv_index, int level_rows, int K, int cin, int cout, const float *x, int ldx,
+                const float *dz, int ldz, float *dW) {
   sps_train *t = c->train;
   const WgPlan &pl = t->wg[conv_index];
   WgradArgs w{};
@@ -413,18 +418,31 @@ int wgrad_launch(sps_ctx *c, hipStream_t st, TKind kind, int conv_index, int lev
   if ((cin & 7) || (cout & 7) || (ldx & 3) || (ldz & 3) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(dz) & 15))
     return fail(SPS_ERR_INVALID, "wgrad: operands must be 16-byte aligned with channel counts in multiples of 8");
   w.out = pl.nwg > 1 ? t->slab + pl.slab_off : dW;
-  const dim3 grid((unsigned)pl.nwg, (unsigned)K, (unsigned)pl.zblocks);
-  const int key = pl.aw * 10 + pl.bw;
-  switch (key) {
-    case 11: wgrad_go<1, 1>(w, grid, st); break;
-    case 12: wgrad_go<1, 2>(w, grid, st); break;
-    case 14: wgrad_go<1, 4>(w, grid, st); break;
-    case 21: wgrad_go<2, 1>(w, grid, st); break;
-    case 22: wgrad_go<2, 2>(w, grid, st); break;
-    case 24: wgrad_go<2, 4>(w, grid, st); break;
-    default: return fail(SPS_ERR_INVALID, "wgrad: no instantiation for a %d x %d block", pl.aw, pl.bw);
-  }
+  if (!((pl.aw == 1 || pl.aw == 2) && (pl.bw == 1 || pl.bw == 2 || pl.bw == 4)))
+    return fail(SPS_ERR_INVALID, "wgrad: no instantiation for a %d x %d block", pl.aw, pl.bw);
+  WgradJobs &js = t->wjobs[wgrad_shape_index(pl.aw, pl.bw)];
+  if (js.n >= WG_MAXJ) return fail(SPS_ERR_INVALID, "wgrad: more than %d layers of one block shape", WG_MAXJ);
+  WgradJob &j = js.j[js.n++];
+  j.a = w;
+  j.nwg = pl.nwg;
+  j.wg0 = js.total;
+  js.total += pl.nwg * K * pl.zblocks;
   return SPS_OK;
+}
+
+template <int AW, int BW>
+void wgrad_go(const WgradJobs &js, hipStream_t st) {
+  if (js.n) hipLaunchKernelGGL((k_wgrad<AW, BW>), dim3((unsigned)js.total), dim3(WG_WAVES * 64), 0, st, js);
+}
+void wgrad_run(sps_ctx *c, hipStream_t st) {
+  sps_train *t = c->train;
+  // the widest blocks first: their workgroups are the longest
+  wgrad_go<2, 4>(t->wjobs[5], st);
+  wgrad_go<2, 2>(t->wjobs[4], st);
+  wgrad_go<1, 4>(t->wjobs[2], st);
+  wgrad_go<2, 1>(t->wjobs[3], st);
+  wgrad_go<1, 2>(t->wjobs[1], st);
+  wgrad_go<1, 1>(t->wjobs[0], st);
 }
 
 // the one reduce launch of a backward: every layer whose k_wgrad ran with more than one workgroup per (k, block)
@@ -613,6 +631,7 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
     if (nz > ZERO_MAX) return fail(SPS_ERR_INVALID, "backward: %d buffers to clear, table holds %d", nz, ZERO_MAX);
     hipLaunchKernelGGL(k_zero_grads, dim3(96, (unsigned)nz), dim3(256), 0, st, z, c->counts, c->cap);
   }
+  t->wjobs.assign(WGRAD_SHAPES, WgradJobs{});
   // head: sigmoid + slice + final
   const ConvSpec &fs = s.convs[s.find_conv("final")];
   const TView b8o = view_of(t, c->b8o);
@@ -627,7 +646,6 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
     const int npair = (is_downsample(ops[oi]) && oi >= 1) ? 2 : 1;
     BnBwd2 jobs{};
     int64_t apply_items = 0;
-    float *dzs[2] = {t->dz, t->dz2};
     for (int j = 0; j < npair; ++j) {
       const TOp &op = ops[oi - j];
       const int ci = s.find_conv(op.name);
@@ -650,7 +668,7 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
       b.bpart = t->bn_bpart + (size_t)j * BN_WG * 2 * BN_MAXC;
       b.dgamma = t->grad + bn.off;
       b.dbeta = t->grad + bn.off + bn.c;
-      b.dZ = dzs[j];
+      b.dZ = t->dzl[ci];
       b.lddz = cs.cout;
       b.dres = op.res.g;
       b.lddr = op.res.ld;
@@ -666,7 +684,7 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
       const int ci = s.find_conv(op.name);
       const ConvSpec &cs = s.convs[ci];
       const int lo = op.out.level;
-      const float *dz = dzs[j];
+      const float *dz = t->dzl[ci];
       int rc = SPS_OK;
       if (op.kind == T_CONV0) {
         hipLaunchKernelGGL(k_conv0_wgrad, dim3(C0_WG), dim3(256), 0, st, c->counts + 0, c->lv[0].view(), dz, 8, 0.5f, t->c0part);
@@ -675,17 +693,17 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
       }
       // weight gradient: pairs of the op's map; data gradient: the transposed map with transposed weights, accumulated
       if (op.kind == T_UP) {
-        rc = wgrad_launch(c, st, T_UP, ci, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
+        rc = wgrad_defer(c, T_UP, ci, lo + 1, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
         if (rc != SPS_OK) return rc;
         // y[child] = x[parent] W[oct]  =>  dx[parent] += sum over children dy[child] W[oct]^T : a gather over the `down` table
         rc = conv_plain(c, st, T_DOWN, lo + 1, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dz, cs.cout, op.in.g, op.in.ld, true);
       } else if (op.kind == T_DOWN) {
-        rc = wgrad_launch(c, st, T_DOWN, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
+        rc = wgrad_defer(c, T_DOWN, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
         if (rc != SPS_OK) return rc;
         // z[parent] = sum over children x[child] W[oct]  =>  dx[child] += dz[parent] W[oct]^T : parent-stationary scatter
         rc = conv_plain(c, st, T_UP, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dz, cs.cout, op.in.g, op.in.ld, true);
       } else {
-        rc = wgrad_launch(c, st, op.kind, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
+        rc = wgrad_defer(c, op.kind, ci, lo, cs.K, cs.cin, cs.cout, op.in.p, op.in.ld, dz, cs.cout, t->grad + cs.w_off);
         if (rc != SPS_OK) return rc;
         rc = conv_plain(c, st, op.kind, lo, cs.K, cs.cout, cs.cin, t->wut + t->wut_off[ci], dz, cs.cout, op.in.g, op.in.ld, true);
       }
@@ -693,6 +711,7 @@ static int train_backward_impl(sps_ctx *c, const float *dscores, const float *sc
     }
     oi -= npair;
   }
+  wgrad_run(c, st);
   {
     const int rc = wgrad_reduce_all(c, st);
     if (rc != SPS_OK) return rc;

@@ -335,7 +335,7 @@ struct WgradArgs {
   const int *nbr;   // [K][ldn] or null (1x1: i = o = row)
   const uint32_t *tmask;  // per 16-row tile, one word per time slice: the offsets for which the tile's table entries were WRITTEN
   const int *n_rows;  // rows of the map (device count)
-  float *out;         // gridDim.x == 1: dW [K][cin][cout]; otherwise the launch's slab [gridDim.x][K][cin][cout]
+  float *out;         // one workgroup per (k, block): dW [K][cin][cout]; otherwise the layer's slab [nwg][K][cin][cout]
   int64_t ldn;
   int ldx, ldz, K, cin, cout, NB, gather_b;  // NB: blocks of 16 BW output channels (blockIdx.z = input block * NB + output block)
   uint32_t x_bytes, dz_bytes;  // extents of the operand buffers from x / dz on (raw buffer loads: an offset beyond them reads zeros)
@@ -343,6 +343,19 @@ struct WgradArgs {
 };
 constexpr int WG_WAVES = 16;
 constexpr int WG_RING = 128;  // pairs a wave can hold: <= 31 left over + 64 new
+// One launch per block shape <AW, BW> carries the weight gradients of ALL layers of that shape (they run at the end of the
+// backward, every layer's dZ kept in a buffer of its own): workgroup b belongs to the job j with wg0[j] <= b < wg0[j + 1]
+// and is workgroup (b - wg0[j]) of that job's (nwg, K, zblocks) grid.  31 launches -> 5; the small layers' launch floors and
+// the big layers' tails overlap.
+constexpr int WG_MAXJ = 16;
+struct WgradJob {
+  WgradArgs a;
+  int nwg, wg0;
+};
+struct WgradJobs {
+  WgradJob j[WG_MAXJ];
+  int n, total;
+};
 
 constexpr uint32_t WG_OOR = 0xFFFFFFFFu;
 // W floats at byte offset `off` of the buffer (WG_OOR: zeros).  Raw buffer loads: a gather is branch-free whatever the
@@ -407,18 +420,23 @@ __device__ inline void wgrad_mfma(const WgradGroup<AW, BW> &w, floatx4 (&acc)[AW
 }
 
 template <int AW, int BW>
-__global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
+__global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradJobs js) {
   __shared__ float red[WG_WAVES][256];
+  int ji = 0;
+  while (ji + 1 < js.n && (int)blockIdx.x >= js.j[ji + 1].wg0) ++ji;
+  const WgradArgs &a = js.j[ji].a;
+  const int job_nwg = js.j[ji].nwg;
+  const int lb = (int)blockIdx.x - js.j[ji].wg0;          // workgroup of the job: (bx, k, block) with bx fastest
+  const int bx = lb % job_nwg, k = (lb / job_nwg) % a.K, bz = lb / (job_nwg * a.K);
   __shared__ __attribute__((aligned(16))) int q_in[WG_WAVES][WG_RING], q_out[WG_WAVES][WG_RING];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int m = lane & 15, q = lane >> 4;
   const int n = *a.n_rows;
   const int gshift = a.gshift, grows = 1 << gshift;
   const int ngroups = (n + grows - 1) >> gshift;
-  const int k = blockIdx.y;
-  const int ab = (int)blockIdx.z / a.NB, bb = (int)blockIdx.z - ab * a.NB;
-  const int nchunk = (int)gridDim.x * WG_WAVES;
-  const int chunk = blockIdx.x * WG_WAVES + wave;
+  const int ab = bz / a.NB, bb = bz - ab * a.NB;
+  const int nchunk = job_nwg * WG_WAVES;
+  const int chunk = bx * WG_WAVES + wave;
   const int per = (ngroups + nchunk - 1) / nchunk;
 #if defined(SPS_WG_ABLATE_LOOP)
   const int g0 = chunk * per, g1 = g0;
@@ -540,7 +558,7 @@ __global__ __launch_bounds__(WG_WAVES * 64) void k_wgrad(WgradArgs a) {
   }
   if (haveB) multiply(B);
   // C/D map: col = lane & 15, row = (lane >> 4) * 4 + i.  The block's tiles go through LDS one after the other.
-  float *__restrict__ dst = a.out + ((size_t)blockIdx.x * a.K + k) * (size_t)(a.cin * a.cout);
+  float *__restrict__ dst = a.out + ((size_t)bx * a.K + k) * (size_t)(a.cin * a.cout);
 #pragma unroll
   for (int ti = 0; ti < AW; ++ti)
 #pragma unroll
