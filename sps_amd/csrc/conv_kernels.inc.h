@@ -42,15 +42,9 @@ struct ConvArgs {
   const unsigned char *rb_k;
   const int *rb_cnt;  // [supertiles][4]
   int rb_supertiles;  // supertiles the rulebook arrays hold
-  // k_conv_ws (coarse levels): slab of the slices' partial sums + one ticket per supertile; workgroups wanted per launch
-  // and the largest slice count
   const int4 *px_order;    // k_conv_px: position -> {supertile, chunks of its three slices}, balanced order (px_order_body), or null
   const int4 *tile_order;  // k_conv: the level's tiles sorted by present-offset count, heaviest first, {tile, mask words} (tile_order_body), or null
   int order_ways;          // > 0: positions are laid out boustrophedon over tiers of this many (positions that share a CU)
-  float *slab;
-  int *ticket;
-  uint32_t slab_bytes;
-  int ws_target, ws_smax;
   // transposed convolution fused into this layer's epilogue (k_conv<..., UNT > 0>, k_conv_px<..., UP>): the tile of output
   // rows this workgroup has just finished IS the parent tile k_upconv would load (minkunet.py:107-146: convtrXpYs2 follows
   // blockX.conv2).  Weights / folded BN of the transposed layer, the stride map's child table (down[k][parent row]) with its
@@ -936,334 +930,6 @@ __global__ __launch_bounds__(NW * 64, MINW) void k_conv_px(ConvArgs a) {
   }
 }
 
-// EXPERIMENTAL, NOT IN THE PRODUCT BUILD (round 3; compiled with -DSPS_DIAG only, tools/ws_sweep.sh).
-// Parity-green, but slower than k_conv on every coarse layer (block5.conv1: 46.9 us against 40.4): with one wave per SIMD and one
-// barrier per stage the MFMA phase alone runs at 2.3 us per 96-MFMA stage and the cross-workgroup slab reduce adds 3 us.
-#if defined(SPS_DIAG)
-// Weight-sharing sparse convolution for the coarse levels (levels 2-4: few rows, wide channels; round 3).
-//   k_conv streams the offset's whole weight block (C_in x C_out, up to 24 KB) from L2 for EVERY 16-row tile: the wide coarse
-//   layers issue one gather and two weight wave-loads per eight MFMAs and are bound by the CU's vector-memory path (a
-//   16-byte-per-lane wave-load costs it about as long as one MFMA costs a SIMD; block5.conv1: 342 MB of weight fragments
-//   through the L1s per launch against 5.9 MB algorithmic).  Here a workgroup owns a SUPERTILE of 64 output rows (wave w =
-//   its 16-row tile w, all column tiles) and one contiguous SLICE of the supertile's present-offset list; the weights of a
-//   STAGE (GK offsets = up to 8 groups of 16 input channels, <= 32 KB) come into LDS ONCE per workgroup by LDS-DMA
-//   (buffer_load ... lds: the per-lane source address picks the unit-major fragment piece, the LDS image of a piece is the
-//   1 KB MFMA B fragment in lane order), double-buffered against the MFMAs, and all four waves read their B fragments with
-//   ds_read_b128; only the A rows are gathered per wave (straight into registers, one stage ahead).  A wave skips the offsets
-//   its own tile lacks (tile mask), so the MFMA count stays tile-granular.
-//   Few supertiles (80 at level 3, 26 at level 4 for a 100k-point scan) cannot fill 256 CUs: the present-offset list is cut
-//   into S slices (S = clamp(ws_target / supertiles, 2, ws_smax), computed from the device-side row count), one workgroup
-//   each; the partial sums meet in a slab in global memory: write-through (sc1) stores, every wave drains them, one relaxed
-//   agent-scope ticket per supertile; the workgroup that draws the last ticket acquires, reads the S partial sums in slice
-//   order (fixed order: bit-reproducible run to run) and runs the epilogue (cdna_hip_programming.md section 5, "in-launch split-K
-//   reduction").  Offsets ascend inside a slice and slices ascend in the sum (App. A.8).
-//   The fused 1x1 downsample branch (DSCIN > 0) is added by the last slice from direct loads.
-constexpr int WS_SMIN = 2;
-constexpr int WS_MAXJ = 48;  // offsets of one slice (81 present offsets at most, S >= 2; < 64: one bit each in a lane mask)
-// first level it serves, workgroups wanted per launch (2.5 per CU), most slices per supertile
-#ifndef SPS_WS_TARGET
-#define SPS_WS_TARGET 640
-#endif
-#ifndef SPS_WS_SMAX
-#define SPS_WS_SMAX 8
-#endif
-#ifndef SPS_WS_FIRST_LEVEL
-#define SPS_WS_FIRST_LEVEL 2   // -DSPS_WS_FIRST_LEVEL=9: every layer on k_conv, as the product build
-#endif
-constexpr int WS_FIRST_LEVEL = SPS_WS_FIRST_LEVEL;
-constexpr int WS_TARGET = SPS_WS_TARGET;
-constexpr int WS_SMAX = SPS_WS_SMAX;
-#if defined(SPS_DIAG) && defined(SPS_WS_ABL)  // diagnostic builds only (tools/variant_sweep.sh): 1 no reduce, 2 no MFMAs, 4 no DMA, 8 no gathers
-constexpr int WS_ABL = SPS_WS_ABL;
-#else
-constexpr int WS_ABL = 0;
-#endif
-typedef __attribute__((address_space(3))) unsigned char lds_byte;
-template <int CIN, int NT, int DSCIN>
-__global__ __launch_bounds__(256, 2) void k_conv_ws(ConvArgs a) {
-  constexpr int NG = CIN / 16;                   // groups of 16 input channels per offset
-  constexpr int GK = NG >= 5 ? 1 : 8 / NG;       // offsets per stage (<= 8 groups: the A operands of a stage are 8 float4)
-  constexpr int PPO = NG * NT;                   // 1-KB weight pieces (group, column tile) per offset
-  constexpr int SP = GK * PPO;                   // pieces per stage
-  constexpr int UPK = CIN / 4;
-  static_assert(CIN % 16 == 0 && DSCIN % 16 == 0 && SP <= 32, "stage geometry");
-  constexpr int WBYTES = 2 * SP * 1024, AOBYTES = 4 * WS_MAXJ * 16 * 4;
-  // ONE shared array (a second __shared__ object next to an LDS-DMA target can cost a vmcnt(0) before every ds_read)
-  __shared__ __attribute__((aligned(16))) unsigned char smem[WBYTES + AOBYTES + 4 * 128 + 16];
-  unsigned char *const wbuf = smem;
-  uint32_t *const ao_all = reinterpret_cast<uint32_t *>(smem + WBYTES);
-  unsigned char *const kl_all = smem + WBYTES + AOBYTES;
-  int *const flag_s = reinterpret_cast<int *>(smem + WBYTES + AOBYTES + 4 * 128);
-  if (a.abort_flag && *a.abort_flag) return;
-  const int count = *a.n_out;
-  const int nst = (count + 63) >> 6, ntiles = (count + 15) >> 4;
-  if (nst == 0) return;
-  const int S = min(a.ws_smax, max(WS_SMIN, a.ws_target / nst));
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int r = lane & 15, q = lane >> 4;
-  uint32_t *const ao = ao_all + wave * (WS_MAXJ * 16);
-  unsigned char *const kl = kl_all + wave * 128;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)a.in, 0, (int)a.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void *)a.Wu, 0, (int)a.wu_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr, 0, (int)a.nbr_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsS = __builtin_amdgcn_make_buffer_rsrc((void *)a.slab, 0, (int)a.slab_bytes, 0x00020000);
-  const uint32_t ldi4 = (uint32_t)a.ldi * 4u, ldn32 = (uint32_t)a.ldn;
-  const uint32_t wlane = (uint32_t)q * (uint32_t)(NT * 256) + (uint32_t)r * 16u;  // this lane's piece of a fragment (unit 4 i + q, column r)
-  float esc[NT], esh[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int col = nt * 16 + r;
-    esc[nt] = col < a.cout ? a.scale[col] : 0.f;
-    esh[nt] = col < a.cout ? a.shift[col] : 0.f;
-  }
-  const int nitems = nst * S;
-  for (int item = blockIdx.x; item < nitems; item += gridDim.x) {
-    const int st = item / S, s = item - st * S;
-    const int row0 = st * 64 + wave * 16;
-    __syncthreads();  // the previous item is done with the shared arrays
-    // ---- present offsets of the supertile (union of its four tile masks) and of this wave's tile
-    uint32_t um[3] = {0u, 0u, 0u}, my[3] = {0u, 0u, 0u};
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int tile = st * 4 + t;
-      if (tile < ntiles) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          const uint32_t m = a.tmask[(size_t)tile * 4 + w] & 0x7FFFFFFu;
-          um[w] |= m;
-          if (t == wave) my[w] = m;
-        }
-      }
-    }
-    int nk;
-    {
-      const uint32_t w01 = lane < 32 ? um[0] : um[1];
-      const bool b0 = (w01 >> (lane & 31)) & 1u, b1 = lane < 32 && ((um[2] >> (lane & 31)) & 1u);
-      const unsigned long long bal0 = __ballot(b0), bal1 = __ballot(b1);
-      const unsigned long long lt = (1ull << lane) - 1ull;
-      const int n0 = __popcll(bal0);
-      if (b0) kl[__popcll(bal0 & lt)] = (unsigned char)((lane >> 5) * 27 + (lane & 31));
-      if (b1) kl[n0 + __popcll(bal1 & lt)] = (unsigned char)(54 + lane);
-      nk = n0 + __popcll(bal1);
-    }
-    __builtin_amdgcn_wave_barrier();
-    const int j0 = (s * nk) / S, j1 = ((s + 1) * nk) / S;
-    const int nj = j1 - j0;  // <= WS_MAXJ (S >= 2)
-    const int nstage = (nj + GK - 1) / GK;
-    // offsets of the slice that this wave's tile has (bit jj of mymask)
-    unsigned long long mymask;
-    {
-      const int k = lane < nj ? (int)kl[j0 + lane] : 0;
-      const int w = k / 27, b = k - 27 * w;
-      const uint32_t mw = w == 0 ? my[0] : (w == 1 ? my[1] : my[2]);
-      mymask = __ballot(lane < nj && ((mw >> b) & 1u));  // (WS_MAXJ <= 64: S >= 2)
-    }
-    // ---- byte offsets of the neighbour rows: ao[jj * 16 + r] (lane (q, r): offsets jj = q + 4 i)
-    {
-      const int row = row0 + r;
-      const bool rv = row < count;
-      uint32_t kv[WS_MAXJ / 4];
-#pragma unroll
-      for (int i = 0; i < WS_MAXJ / 4; ++i) kv[i] = kl[j0 + max(0, min(q + 4 * i, nj - 1))];  // unconditional LDS reads
-      int vals[WS_MAXJ / 4];
-#pragma unroll
-      for (int i = 0; i < WS_MAXJ / 4; ++i) {
-        const int jj = q + 4 * i;
-        const bool act = rv && jj < nj && ((mymask >> jj) & 1ull);
-        const uint32_t off = act ? (kv[i] * ldn32 + (uint32_t)row) * 4u : OOR;
-        vals[i] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, off, 0, 0);
-      }
-#pragma unroll
-      for (int i = 0; i < WS_MAXJ / 4; ++i) {
-        const int jj = q + 4 * i;
-        const bool act = rv && jj < nj && ((mymask >> jj) & 1ull);
-        ao[jj * 16 + r] = (act && vals[i] >= 0) ? (uint32_t)vals[i] * ldi4 : OOR;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    floatx4 acc[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    u32x4 an[GK * NG];
-#pragma unroll
-    for (int i = 0; i < GK * NG; ++i) an[i] = u32x4{0u, 0u, 0u, 0u};
-    // Operands of stage js: this wave's share of the weight pieces by LDS-DMA into buffer js & 1, and the gathers of its
-    // tile's A rows into an[].  The LDS reads they need (offsets of the stage, neighbour byte offsets) are done by
-    // stage_heads() BEFORE any DMA of the stage is issued: an LDS read behind an LDS-DMA in flight makes hipcc wait for the
-    // DMA.  issue_part(js, idx) issues the idx-th of the stage's NPART shares (a share = the gather of group idx and
-    // NPW / NPART DMA pieces): the main loop interleaves the shares of stage js + 1 with the MFMA blocks of stage js --
-    // a vector-memory instruction issued among MFMAs costs the wave ~60 cycles of the 32 x 16 the block occupies the
-    // matrix pipe, issued in front of them it delays them by that much (measured: loads and MFMAs of a stage added up).
-    constexpr int NPART = GK * NG;          // MFMA blocks (groups) per stage
-    constexpr int NPW = (SP + 3) / 4;       // DMA pieces per wave and stage
-    int kvl = 0;
-    uint32_t abase[GK];
-    auto stage_heads = [&](int js) {
-      const int jb = js * GK;
-      kvl = (int)kl[j0 + min(jb + (lane & 7), max(nj - 1, 0))];  // lane g (< 8): offset of slot g
-#pragma unroll
-      for (int g = 0; g < GK; ++g) abase[g] = ao[min(jb + g, WS_MAXJ - 1) * 16 + r] + (uint32_t)q * 16u;
-    };
-    auto issue_part = [&](int js, int idx) {
-      const int jb = js * GK;
-      lds_byte *const dst = (lds_byte *)(wbuf + (js & 1) * (SP * 1024));
-#pragma unroll
-      for (int pp = 0; pp < NPW; ++pp) {
-        if (pp * NPART / NPW != idx) continue;  // compile-time after unrolling
-        const int p = wave + 4 * pp;  // piece: offset slot g of the stage, group i, column tile nt
-        const int g = p / PPO, rem = p - g * PPO;
-        if (!(WS_ABL & 4) && p < SP && jb + g < nj) {
-          const int k = __builtin_amdgcn_readlane(kvl, g);
-          const int i = rem / NT, nt = rem - i * NT;
-          const uint32_t src = ((uint32_t)(k * UPK + 4 * i) * (uint32_t)NT + (uint32_t)nt) * 256u + wlane;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, dst + p * 1024, 16, src, 0, 0, 0);
-        }
-      }
-      const int g = idx / NG, i = idx - g * NG;
-      const int jj = jb + g;
-      if (!(WS_ABL & 8) && jj < nj && ((mymask >> jj) & 1ull))  // wave-uniform
-        an[idx] = __builtin_amdgcn_raw_buffer_load_b128(rsA, abase[g] + (uint32_t)i * 64u, 0, 0);
-    };
-    if (nstage > 0) {
-      stage_heads(0);
-#pragma unroll
-      for (int idx = 0; idx < NPART; ++idx) issue_part(0, idx);
-    }
-    for (int js = 0; js < nstage; ++js) {
-      // the operands of stage js have landed (this wave's gathers and its share of the DMA); after the barrier so have the
-      // other waves' shares, and every wave is done reading the other buffer (stage js - 1)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      u32x4 ac[GK * NG];
-#pragma unroll
-      for (int i = 0; i < GK * NG; ++i) ac[i] = an[i];
-      const bool more = js + 1 < nstage;
-      if (more) stage_heads(js + 1);
-      const unsigned char *const wb = wbuf + (js & 1) * (SP * 1024) + lane * 16;
-      if (WS_ABL & 2) {  // diagnostic builds: keep the gathered operands alive without the MFMAs
-#pragma unroll
-        for (int i = 0; i < GK * NG; ++i) asm volatile("" ::"v"(ac[i].x), "v"(ac[i].y), "v"(ac[i].z), "v"(ac[i].w));
-      }
-#pragma unroll
-      for (int g = 0; g < GK; ++g) {
-        const int jj = js * GK + g;
-        const bool on = !(WS_ABL & 2) && jj < nj && ((mymask >> jj) & 1ull);  // wave-uniform
-        // B fragments of group i + 1 are read while the MFMAs of group i run; the MFMA steps rotate over the column
-        // tiles (a step's successor on the same accumulator is NT instructions away)
-        floatx4 b[2][NT];
-        if (on) {
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) b[0][nt] = *reinterpret_cast<const floatx4 *>(wb + ((g * NG) * NT + nt) * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < NG; ++i) {
-          if (more) issue_part(js + 1, g * NG + i);
-          if (on) {
-            if (i + 1 < NG) {
-#pragma unroll
-              for (int nt = 0; nt < NT; ++nt)
-                b[(i + 1) & 1][nt] = *reinterpret_cast<const floatx4 *>(wb + ((g * NG + i + 1) * NT + nt) * 1024);
-            }
-            const u32x4 av = ac[g * NG + i];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.x), b[i & 1][nt].x, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.y), b[i & 1][nt].y, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.z), b[i & 1][nt].z, acc[nt], 0, 0, 0);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(av.w), b[i & 1][nt].w, acc[nt], 0, 0, 0);
-          }
-        }
-      }
-    }
-    // ---- fused residual branch r = downsample(x) = x[row] @ Wds (identity map), last slice only
-    if (DSCIN > 0 && s == S - 1) {
-      const __amdgpu_buffer_rsrc_t rsA2 = __builtin_amdgcn_make_buffer_rsrc((void *)a.in2, 0, (int)a.in2_bytes, 0x00020000);
-      const int row = row0 + r;
-      const uint32_t rowoff = row < count ? (uint32_t)row * ((uint32_t)a.ldi2 * 4u) + (uint32_t)q * 16u : OOR;
-      const uint32_t wbase = (uint32_t)(81 * UPK) * (uint32_t)(NT * 256) + wlane;
-      constexpr int NG2 = DSCIN / 16;
-      u32x4 va[NG2 > 0 ? NG2 : 1];
-#pragma unroll
-      for (int i = 0; i < NG2; ++i) va[i] = __builtin_amdgcn_raw_buffer_load_b128(rsA2, rowoff + (uint32_t)i * 64u, 0, 0);
-#pragma unroll
-      for (int i = 0; i < NG2; ++i) {
-        u32x4 vb[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          vb[nt] = __builtin_amdgcn_raw_buffer_load_b128(rsW, wbase + (uint32_t)(4 * i * NT + nt) * 256u, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].x), __uint_as_float(vb[nt].x), acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].y), __uint_as_float(vb[nt].y), acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].z), __uint_as_float(vb[nt].z), acc[nt], 0, 0, 0);
-          acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(va[i].w), __uint_as_float(vb[nt].w), acc[nt], 0, 0, 0);
-        }
-      }
-    }
-    // ---- partial sums -> slab (write-through), ticket; the last arriver reduces in slice order
-    if (!(WS_ABL & 1)) {
-      const uint32_t sbase = (uint32_t)((item * 4 + wave) * NT) * 1024u + (uint32_t)lane * 16u;
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        u32x4 v;
-        v.x = __float_as_uint(acc[nt][0]), v.y = __float_as_uint(acc[nt][1]), v.z = __float_as_uint(acc[nt][2]), v.w = __float_as_uint(acc[nt][3]);
-        __builtin_amdgcn_raw_buffer_store_b128(v, rsS, sbase + (uint32_t)nt * 1024u, 0, 16);  // aux 16 = sc1
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its stores
-      __syncthreads();
-      if (threadIdx.x == 0) *flag_s = __hip_atomic_fetch_add(a.ticket + st, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (*flag_s != S - 1) continue;  // workgroup-uniform
-      if (threadIdx.x == 0) {
-        __hip_atomic_store(a.ticket + st, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-      for (int s0 = 0; s0 < S; s0 += 4) {  // four slices in flight; slices past S read zeros (x + 0 = x)
-        u32x4 pv[4][NT];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const uint32_t o = s0 + u < S ? (uint32_t)(((st * S + s0 + u) * 4 + wave) * NT + nt) * 1024u + (uint32_t)lane * 16u : OOR;
-            pv[u][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsS, o, 0, 16);
-          }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            acc[nt][0] += __uint_as_float(pv[u][nt].x), acc[nt][1] += __uint_as_float(pv[u][nt].y);
-            acc[nt][2] += __uint_as_float(pv[u][nt].z), acc[nt][3] += __uint_as_float(pv[u][nt].w);
-          }
-      }
-    }
-    // ---- epilogue.  C/D map: col = lane & 15, row = (lane >> 4) * 4 + i
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int col = nt * 16 + r;
-      if (col >= a.cout) continue;
-      const float sc = esc[nt], sh = esh[nt];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int ro = row0 + q * 4 + i;
-        if (ro >= count) continue;
-        float y = acc[nt][i] * sc + sh;
-        if (a.res) y += a.res[(size_t)ro * a.ldr + col];
-        if (a.relu) y = fmaxf(y, 0.f);
-        a.out[(size_t)ro * a.ldo + col] = y;
-      }
-    }
-  }
-}
-#endif  // SPS_DIAG
-
 // Transposed (up-sampling) convolution, parent-stationary (App. A.10: every fine voxel v receives exactly one
 // term, in[parent(v)] @ W[oct(v)]).  Run output-stationary through k_conv it executes all 8 offsets for every
 // fine tile although one row in eight is live per offset; here a workgroup owns a tile of 16 PARENT rows:
@@ -1384,8 +1050,10 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
     const int which = (int)blockIdx.x;
     if (which < NLV - TILE_ORDER_FIRST_LEVEL)
       tile_order_body(to, which);
-    else
+    else if (which < NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS)
       px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
+    else
+      om_build_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS));
     return;
   }
   const int bid = (int)blockIdx.x - gto;
@@ -1522,8 +1190,10 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
     const int which = (int)blockIdx.x;
     if (which < NLV - TILE_ORDER_FIRST_LEVEL)
       tile_order_body(to, which);
-    else
+    else if (which < NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS)
       px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
+    else
+      om_build_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS));
     return;
   }
   const int bid = (int)blockIdx.x - gto;

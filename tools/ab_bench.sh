@@ -5,6 +5,7 @@ reps=$1; args=$2; shift 2
 mkdir -p gpurun_out
 for r in $(seq 1 $reps); do
   for t in "$@"; do
+    [ -f tools/ab/lib_$t.so ] || { echo "SKIPPED $t: tools/ab/lib_$t.so does not exist (tools/ab_build.sh $t ...)"; continue; }
     SPS_LIB=tools/ab/lib_$t.so python3 bench.py $args > gpurun_out/ab_${t}_$r.json 2>> gpurun_out/ab.err || echo "FAILED $t $r"
   done
 done
