@@ -338,10 +338,8 @@ int sps_get_nbr(sps_ctx *ctx, int which, int32_t *nbr_dev);
  *   which = 6..9: stride-2 map into coarse level which - 5 (K = 8, k = dx + 2dy + 4dz; rows = coarse voxels, entries = fine
  *                 rows; the transposed convolutions read the same table with the roles swapped).
  * source = 0: the output-stationary neighbour / child table; source = 1 (which = 0..4 at the pair-exact levels): decoded from
- * the RULEBOOK the pair-exact convolutions read; source = 2 (which = 2..4 in a context with compact arenas): decoded from the
- * OFFSET-MAJOR rulebook the coarse-level convolutions read (per offset the list of {input row, product slot}, per output row
- * and time slice a run of product slots: every pair must be reachable from its row's run, offsets ascending);
- * *n_entries (may be NULL) = number of pairs it holds (malformed or duplicate entries fail the call). */
+ * the RULEBOOK the pair-exact convolutions read; *n_entries (may be NULL) = number of pairs it holds (malformed or duplicate
+ * entries fail the call). */
 int sps_get_kernel_map(sps_ctx *ctx, int which, int source, int32_t *out_dev, int64_t *n_entries);
 /* Per-voxel logits of the last forward, float32 [V_0]. */
 int sps_get_logits(sps_ctx *ctx, float *logits_dev);

@@ -346,8 +346,7 @@ class Context:
 
     def kernel_map(self, which: int, source: int = 0):
         """Dense int32 [K, V_out] table of a kernel map of the last forward (include/sps_hip.h: sps_get_kernel_map), on the
-        device; with source = 1 (supertile rulebook of levels 0-1) or 2 (offset-major rulebook of the coarse levels of a
-        compact context) also the number of pairs the rulebook holds."""
+        device; with source = 1 also the number of pairs the rulebook holds."""
         import torch
         counts = self.level_counts()
         level = which if which <= 4 else (0 if which == 5 else which - 5)
@@ -355,7 +354,7 @@ class Context:
         out = torch.empty((K, counts[level]), dtype=torch.int32, device=f"cuda:{self.device}")
         n = C.c_int64()
         check(lib.sps_get_kernel_map(self.handle, which, source, out.data_ptr(), C.byref(n)))
-        return (out, n.value) if source >= 1 else out
+        return (out, n.value) if source == 1 else out
 
     def map_pairs(self, which: int):
         out = (C.c_int64 * 125)()

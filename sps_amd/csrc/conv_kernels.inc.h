@@ -1050,10 +1050,8 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
     const int which = (int)blockIdx.x;
     if (which < NLV - TILE_ORDER_FIRST_LEVEL)
       tile_order_body(to, which);
-    else if (which < NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS)
-      px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
     else
-      om_build_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS));
+      px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
     return;
   }
   const int bid = (int)blockIdx.x - gto;
@@ -1190,10 +1188,8 @@ __global__ __launch_bounds__(256) void k_conv0_feat(const int *__restrict__ n_ou
     const int which = (int)blockIdx.x;
     if (which < NLV - TILE_ORDER_FIRST_LEVEL)
       tile_order_body(to, which);
-    else if (which < NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS)
-      px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
     else
-      om_build_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS));
+      px_order_body(to, which - (NLV - TILE_ORDER_FIRST_LEVEL));
     return;
   }
   const int bid = (int)blockIdx.x - gto;

@@ -199,10 +199,7 @@ __device__ inline int block_reduce_sum(int v, int *lds) {
 // counters behind the 16 level counters (all cleared by the first kernel of the forward):
 //   counts[TICKET + l]  logical workgroup ids of level l's ranking pass, handed out in the order the workgroups START
 //   counts[TOCC]        bit t set = some block has biased time index t (the time axis is never strided: valid at every level)
-//   counts[OMC + 84 (l - OM_FIRST_LEVEL) + k]  offset-major rulebook of level l (map_kernels.inc.h): pairs of offset k = 0..80 handed out so far,
-//                       [.. + 81] product slots handed out so far
-constexpr int TICKET = 16, TOCC = 24, OMC = 32, OM_FIRST_LEVEL = 2, OM_CSTRIDE = 84, N_COUNTERS = 32 + 256;
-static_assert(OMC + OM_CSTRIDE * (SPS_NUM_LEVELS - OM_FIRST_LEVEL) <= N_COUNTERS && N_COUNTERS % 4 == 0, "offset-major counters");
+constexpr int TICKET = 16, TOCC = 24, N_COUNTERS = 32;
 
 // ---- single-pass ranking ------------------------------------------------------------------------------------------------
 // Sources of level 0 are the points, of levels >= 1 the level-0 blocks.  A source is the FIRST of its block when

@@ -387,46 +387,6 @@ __global__ void k_export_rulebook(const uint32_t *__restrict__ rb_e, const unsig
   }
 }
 
-// ... or decoded from the OFFSET-MAJOR rulebook the coarse-level convolutions read (sps_get_kernel_map source 2), in the two
-// steps the convolution itself takes: (1) every list entry claims its product slot (slot_k / slot_in pre-filled with -1; a
-// slot claimed twice is malformed), (2) every (time slice, row) walks its slot run: the offsets found there must belong to
-// the slice and ascend (the sum's order), out[k * n + u] = input row.  entries[0] counts the decoded pairs, [1] the malformed.
-__global__ void k_export_om_claim(const uint2 *__restrict__ ome, int64_t ldn, const int *__restrict__ cnt, int slots_cap,
-                                  int *__restrict__ slot_k, int *__restrict__ slot_in, unsigned long long *__restrict__ entries) {
-  const int k = blockIdx.y;
-  const int nk = cnt[k], used = cnt[81];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += gridDim.x * blockDim.x) {
-    const uint2 e = ome[(size_t)k * ldn + i];
-    if ((int)e.y < 0 || (int)e.y >= used || (int)e.y >= slots_cap) {
-      atomicAdd(&entries[1], 1ull);
-      continue;
-    }
-    if (atomicExch(&slot_k[e.y], k) != -1) atomicAdd(&entries[1], 1ull);
-    slot_in[e.y] = (int)e.x;
-  }
-}
-__global__ void k_export_om_rows(const int2 *__restrict__ seg, int64_t ldn, const int *__restrict__ n_ptr, const int *__restrict__ cnt,
-                                 const int *__restrict__ slot_k, const int *__restrict__ slot_in, int *__restrict__ out,
-                                 unsigned long long *__restrict__ entries) {
-  const int n = *n_ptr, used = cnt[81];
-  const int s = blockIdx.y;
-  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < n; u += gridDim.x * blockDim.x) {
-    const int2 sg = seg[(size_t)s * ldn + u];
-    int last = -1;
-    for (int r = 0; r < sg.y; ++r) {
-      const int slot = sg.x + r;
-      const int k = slot >= 0 && slot < used ? slot_k[slot] : -1;
-      if (k < 0 || k / 27 != s || k <= last) {
-        atomicAdd(&entries[1], 1ull);
-        continue;
-      }
-      last = k;
-      out[(size_t)k * n + u] = slot_in[slot];
-      atomicAdd(&entries[0], 1ull);
-    }
-  }
-}
-
 __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slice_words, const int *__restrict__ n_ptr,
                               const uint32_t *__restrict__ tmask, unsigned long long *__restrict__ pairs) {
   const int n = *n_ptr;
@@ -465,18 +425,6 @@ struct TileOrderArgs {
   const int *rb_cnt[NLV];
   int *px_sorted[NLV];
   int4 *px_order[NLV];
-  // OFFSET-MAJOR rulebook of the 3x3x3x3 map (round 5: levels >= OM_FIRST_LEVEL of a compact inference context, else null;
-  // built by om_build_body below, read by k_om_gemm / k_om_sum, om_kernels.inc.h).  Per offset k the list of the map's pairs as
-  // ME's kernel map holds them (App. A.8), each with the slot of its PRODUCT: the products of one output row and time slice
-  // occupy consecutive slots, offsets ascending, so the row's sum is a walk over contiguous memory in ME's accumulation order.
-  const int *nbr3[NLV];  // the level's neighbour table (k_maps) the lists are compacted from
-  int64_t ldn[NLV];
-  uint2 *om_e[NLV];      // [81][ldn] {input row, product slot}; entries [0, counts[OMC + ...k]) of every offset are valid
-  int2 *om_seg[NLV];     // [3][ldn]  {first product slot, pairs} of (time slice, output row)
-  int om_pcap[NLV];      // product slots the level may hand out (beyond it: the forward is aborted, arena overflow)
-  int om_chunk_off[NLV + 1];  // workgroups per level and time slice
-  int *om_counts;        // = counts (written: the counters behind OMC, counts[ABORT])
-  int *err;              // sticky error flags of the context (bit 1: capacity exceeded)
 };
 // start[w] = number of elements in buckets heavier than w (heaviest first), for nb <= 384 buckets: one wave, six buckets per lane
 __device__ inline void bucket_starts_desc(const int *hist, int *start, int nb) {
@@ -527,114 +475,6 @@ __device__ inline void tile_order_body(const TileOrderArgs &a, int which) {
     const uint4 m = *reinterpret_cast<const uint4 *>(tm + (size_t)t * 4);
     const int w = __popc(m.x & 0x7FFFFFFu) + __popc(m.y & 0x7FFFFFFu) + __popc(m.z & 0x7FFFFFFu);
     sorted[start[w] + atomicAdd(&cursor[w], 1)] = make_int4(t, (int)m.x, (int)m.y, (int)m.z);  // (the order inside a bucket varies from run to run: scheduling only)
-  }
-}
-
-// Offset-major rulebook of one level and time slice (TileOrderArgs::om_e), compacted from the neighbour table k_maps has just
-// written -- hosted by the conv0 launch like the two order bodies: it runs in the shadow of the convolution's own
-// workgroups, and the first layer that reads it is several launches away.  One thread = one (row, time slice): its up to 27
-// table entries (those whose tile-mask bit is set were written) come in with one round trip; the WAVE then reserves its
-// place in the 27 per-offset lists and its rows' product slots with ONE atomic round trip (lane j: offset j, lane 27: the
-// slots) and writes the entries.  The order of the waves inside a list, and of the rows' slot runs inside the product buffer,
-// varies from run to run; the product of a pair always lands in its row's run at the place of its offset: no result depends on it.
-__device__ inline void om_build_body(const TileOrderArgs &a, int bid) {
-  const int per_slice = a.om_chunk_off[NLV];
-  const int slice = bid / per_slice;
-  bid -= slice * per_slice;
-  int l = OM_FIRST_LEVEL;
-  while (l + 1 < NLV && bid >= a.om_chunk_off[l + 1]) ++l;
-  const int local = bid - a.om_chunk_off[l];
-  const int nchunks = a.om_chunk_off[l + 1] - a.om_chunk_off[l];
-  uint2 *__restrict__ ome = a.om_e[l];
-  if (!ome) return;
-  const int aborted = a.counts[ABORT], n = a.counts[l];  // (one round trip)
-  if (aborted) return;
-  int2 *__restrict__ omseg = a.om_seg[l];
-  int *__restrict__ omc = a.om_counts + OMC + OM_CSTRIDE * (l - OM_FIRST_LEVEL);
-  const int64_t ldn = a.ldn[l];
-  const uint32_t ldn32 = (uint32_t)ldn;
-  const int lane = threadIdx.x & 63;
-  const int nround = (n + 255) & ~255;  // whole workgroups take part in the barriers
-  const int wave = (int)(threadIdx.x >> 6);
-  __shared__ int om_s[5][28];
-  const unsigned long long ltm = (1ull << lane) - 1ull;
-  const uint32_t *__restrict__ tm = a.tm3[l];
-  const __amdgpu_buffer_rsrc_t rsN = __builtin_amdgcn_make_buffer_rsrc((void *)a.nbr3[l], 0, (int)(81u * ldn32 * 4u), 0x00020000);
-  for (int u = local * 256 + (int)threadIdx.x; u < nround; u += nchunks * 256) {
-    const bool ok = u < n;
-    const uint32_t w_raw = tm[(size_t)(u >> 4) * 4 + slice];  // (rows [n, nround) have mask words: capacities are multiples of 1024)
-    const uint32_t w = ok ? w_raw : 0u;
-    // (no wave leaves the loop body early: the workgroup meets at two barriers per iteration; u is workgroup-uniform in range)
-    // pass 1: which offsets the row has (nine table entries in flight at a time: the body shares the conv0 kernel's registers)
-    uint32_t pm = 0u;
-    if (__any(w != 0u)) {
-#pragma unroll 1
-      for (int j0 = 0; j0 < 27; j0 += 9) {
-        int row[9];
-#pragma unroll
-        for (int j = 0; j < 9; ++j)
-          row[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, (w >> (j0 + j)) & 1u ? ((uint32_t)(27 * slice + j0 + j) * ldn32 + (uint32_t)u) * 4u : 0xFFFFFFFFu, 0, 0);
-#pragma unroll
-        for (int j = 0; j < 9; ++j) pm |= (((w >> (j0 + j)) & 1u) && row[j] >= 0) ? 1u << (j0 + j) : 0u;
-      }
-    }
-    const int cl = __popc(pm);
-    int inc = cl;  // inclusive scan of the rows' pair counts over the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int y = __shfl_up(inc, o, 64);
-      if (lane >= o) inc += y;
-    }
-    const int total = __shfl(inc, 63, 64);
-    int mine = 0;  // lane j < 27: pairs of offset j in this wave
-#pragma unroll
-    for (int j = 0; j < 27; ++j) {
-      const int cj = __popcll(__ballot((pm >> j) & 1u));
-      mine = lane == j ? cj : mine;
-    }
-    if (lane == 27) mine = total;
-    // ONE atomic per workgroup and counter (device-scope atomics on one address serialise at the memory side: with one per
-    // wave the 240 waves of a level-2 slice queued for ~20 us): the four waves' counts meet in LDS, wave 0 reserves for all
-    __syncthreads();  // (the previous iteration's readers are done with om_s)
-    if (lane < 28) om_s[wave][lane] = mine;
-    __syncthreads();
-    if (wave == 0 && lane < 28) {
-      const int all = om_s[0][lane] + om_s[1][lane] + om_s[2][lane] + om_s[3][lane];
-      om_s[4][lane] = all > 0 ? atomicAdd(omc + (lane < 27 ? 27 * slice + lane : 81), all) : 0;
-    }
-    __syncthreads();
-    int got = 0;
-    if (lane < 28) {
-      got = om_s[4][lane];
-      for (int v = 0; v < wave; ++v) got += om_s[v][lane];
-    }
-    const int first = __shfl(got, 27, 64);
-    // the level's product buffer is full: abort the forward like any arena overflow.  (The entries below are still written --
-    // the lists themselves cannot overflow -- with slot numbers nobody will read: every later kernel of the forward exits.)
-    if (lane == 27 && first + total > a.om_pcap[l]) {
-      atomicOr(&a.om_counts[ABORT], 1);
-      atomicOr(a.err, 2);
-    }
-    int dst = first + inc - cl;
-    if (ok) omseg[(size_t)slice * ldn + u] = make_int2(dst, cl);
-    if (!__any(pm != 0u)) continue;
-    // pass 2: the entries (the table entries again: cache hits)
-#pragma unroll 1
-    for (int j0 = 0; j0 < 27; j0 += 9) {
-      int row[9];
-#pragma unroll
-      for (int j = 0; j < 9; ++j)
-        row[j] = (int)__builtin_amdgcn_raw_buffer_load_b32(rsN, (pm >> (j0 + j)) & 1u ? ((uint32_t)(27 * slice + j0 + j) * ldn32 + (uint32_t)u) * 4u : 0xFFFFFFFFu, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 9; ++j) {
-        const bool has = (pm >> (j0 + j)) & 1u;
-        const int at = __builtin_amdgcn_readlane(got, j0 + j) + __popcll(__ballot(has) & ltm);
-        if (has) {
-          ome[(size_t)(27 * slice + j0 + j) * ldn + at] = make_uint2((uint32_t)row[j], (uint32_t)dst);
-          ++dst;
-        }
-      }
-    }
   }
 }
 

@@ -129,27 +129,10 @@ int fail(int code, const char *fmt, ...) {
 #ifndef SPS_PX_DEFAULT
 #define SPS_PX_DEFAULT 3
 #endif
-// offset-major pair-exact convolutions (k_om_gemm + k_om_sum, om_kernels.inc.h): bit l = the 3x3x3x3 layers of level l run
-// them in compact inference contexts (levels >= OM_FIRST_LEVEL only); product slots per row of the level's capacity
-#ifndef SPS_OM_LEVELS
-#define SPS_OM_LEVELS 28
-#endif
-#ifndef SPS_OM_PAIRS_PER_ROW
-#define SPS_OM_PAIRS_PER_ROW 16
-#endif
-// ... and which of those levels' ten layers actually do: bit i = the i-th of block2.conv1, block2.conv2, block3.conv1, block3.conv2,
-// block4.conv1, block4.conv2, block5.conv1, block5.conv2, block6.conv1, block6.conv2 (the others keep k_conv)
-#ifndef SPS_OM_LAYERS
-#define SPS_OM_LAYERS 1023
-#endif
-#ifndef SPS_OM_RT
-#define SPS_OM_RT 2  // row tiles (16 pairs) per wave of k_om_gemm
-#endif
 #include "keys_hash.inc.h"
 #include "grid_kernels.inc.h"
 #include "map_kernels.inc.h"
 #include "conv_kernels.inc.h"
-#include "om_kernels.inc.h"
 #include "aux_kernels.inc.h"
 #include "netspec.inc.h"
 #include "train_kernels.inc.h"
@@ -192,10 +175,6 @@ struct Level {
   uint32_t *rb_e = nullptr;       // [cap/64][PX_CH_MAX][16] pair entries
   unsigned char *rb_k = nullptr;  // [cap/64][PX_KSTRIDE] offset of each chunk
   int *rb_cnt = nullptr;          // [cap/64][4] chunks per time slice
-  // offset-major rulebook of the 3x3x3x3 map (levels that run k_om_gemm / k_om_sum in compact inference contexts)
-  uint2 *om_e = nullptr;          // [81][cap] {input row, product slot}
-  int2 *om_seg = nullptr;         // [3][cap] {first product slot, pairs} per (time slice, row)
-  int64_t om_pcap = 0;            // product slots of the level
   LevelView view() const { return LevelView{vblock, vbit, bkey, bmask, bbase, badj, bparent, bchild, bmb}; }
 };
 
@@ -295,9 +274,6 @@ struct sps_ctx {
   float *x2 = nullptr, *b2t = nullptr, *cat6 = nullptr, *b6t = nullptr, *b6o = nullptr;
   float *x3 = nullptr, *b3t = nullptr, *cat5 = nullptr, *b5t = nullptr, *b5o = nullptr;
   float *x4 = nullptr, *b4t = nullptr, *b4o = nullptr;
-  // offset-major convolutions: the product buffer shared by the layers of a forward ([pcap + rows][C_out] of the layer at hand)
-  float *om_prod = nullptr;
-  size_t om_prod_bytes = 0;
   // per-stage hipEvent profiling (sps_profile_*): off by default
   bool prof = false;
   std::vector<hipEvent_t> prof_ev;
@@ -325,28 +301,6 @@ namespace {
 int px_levels() {
   static const int m = [] { const char *e = diag_env("SPS_PX"); return (e ? atoi(e) : SPS_PX_DEFAULT) & ((1 << PX_LEVELS) - 1); }();
   return m;
-}
-
-// levels whose 3x3x3x3 layers run offset-major (k_om_gemm + k_om_sum) in a compact context.  SPS_OM = bit mask (DIAGNOSTICS)
-int om_levels() {
-  static const int m = [] {
-    const char *e = diag_env("SPS_OM");
-    return (e ? atoi(e) : SPS_OM_LEVELS) & (((1 << SPS_NUM_LEVELS) - 1) & ~((1 << OM_FIRST_LEVEL) - 1));
-  }();
-  return m;
-}
-// ... of THIS context: compact arenas only (their overflow protocol -- abort, NaN scores, SPS_ERR_NOMEM, dense sizes from then
-// on -- also covers the product buffer; a dense context cannot overflow and keeps the output-stationary kernels)
-inline bool om_level(const sps_ctx *c, int l) {
-  return c->compact && l >= OM_FIRST_LEVEL && l < SPS_NUM_LEVELS && ((om_levels() >> l) & 1) && c->lv[l].om_e != nullptr;
-}
-// ... and one of its layers (blockB.0.convC, B = 2..6)
-inline bool om_layer(const sps_ctx *c, const char *name, int level) {
-  static const int m = [] { const char *e = diag_env("SPS_OM_LAYERS"); return e ? atoi(e) : SPS_OM_LAYERS; }();
-  if (!om_level(c, level) || std::strncmp(name, "block", 5) != 0) return false;
-  const int b = name[5] - '0', cv = name[std::strlen(name) - 1] - '1';
-  if (b < 2 || b > 6 || cv < 0 || cv > 1) return false;
-  return (m >> (2 * (b - 2) + cv)) & 1;
 }
 
 int dev_alloc(sps_ctx *c, void **p, size_t bytes) {
@@ -391,7 +345,6 @@ int reserve(sps_ctx *c, int64_t n) {
   c->hcapl[0] = next_pow2(2 * cap);
   for (int l = 1; l < SPS_NUM_LEVELS; ++l) c->hcapl[l] = c->compact ? next_pow2(2 * c->bcapl[0]) : c->hcapl[0];
   const int64_t hcap = c->hcapl[0];
-  int64_t om_bytes = 0;  // product buffer of the offset-major convolutions (largest level)
   int64_t hslots = 0;
   for (int l = 0; l < SPS_NUM_LEVELS; ++l) hslots += c->hcapl[l];
   c->hash_slots = hslots;
@@ -460,18 +413,6 @@ int reserve(sps_ctx *c, int64_t n) {
       }
       if (l > 0) {
         ALLOC(L.down, int, 8 * rows);
-      }
-      L.om_e = nullptr, L.om_seg = nullptr, L.om_pcap = 0;
-      if (c->compact && l >= OM_FIRST_LEVEL && ((om_levels() >> l) & 1)) {
-        // widest 3x3x3x3 layer of the level decides the bytes of a product slot; every byte offset must fit a buffer descriptor
-        const int64_t pcap = (int64_t)SPS_OM_PAIRS_PER_ROW * rows;
-        const int64_t cmax = l == 2 ? 32 : 64;
-        if ((pcap + rows) * cmax * 4 < 0xFFFF0000ll && 81 * rows * 8 < 0xFFFF0000ll) {
-          ALLOC(L.om_e, uint2, 81 * rows);
-          ALLOC(L.om_seg, int2, 3 * rows);
-          L.om_pcap = pcap;
-          om_bytes = std::max<int64_t>(om_bytes, (pcap + rows) * cmax * 4);
-        }
       }
       L.tile_order = nullptr;
       if (TILE_ORDER != 0 && l >= TILE_ORDER_FIRST_LEVEL) ALLOC(L.tile_order, int4, rows / 16);
@@ -543,11 +484,6 @@ int reserve(sps_ctx *c, int64_t n) {
   ALLOC(c->x4, float, 32 * cl[4]);
   ALLOC(c->b4t, float, 64 * cl[4]);
   ALLOC(c->b4o, float, 64 * cl[4]);
-  c->om_prod = nullptr, c->om_prod_bytes = 0;
-  if (om_bytes > 0) {
-    ALLOC(c->om_prod, float, om_bytes / 4);
-    c->om_prod_bytes = (size_t)om_bytes;
-  }
   c->cap = cap;
   c->hcap = hcap;
   c->last_n = 0;
@@ -841,19 +777,6 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
       }
       to.counts = c->counts;
       gto = NLV - TILE_ORDER_FIRST_LEVEL + PX_LEVELS;
-      // offset-major rulebooks of the coarse levels (compact inference contexts), compacted from the neighbour tables
-      to.om_counts = c->counts, to.err = c->err;
-      int offom = 0;
-      for (int l = 0; l < NLV; ++l) {
-        to.om_chunk_off[l] = offom;
-        if (l >= OM_FIRST_LEVEL && om_level(c, l) && c->lv[l].nbr3) {
-          to.nbr3[l] = c->lv[l].nbr3, to.ldn[l] = c->capl[l];
-          to.om_e[l] = c->lv[l].om_e, to.om_seg[l] = c->lv[l].om_seg, to.om_pcap[l] = (int)c->lv[l].om_pcap;
-          offom += grid_for(c->cap >> l, 256, 1024);
-        }
-      }
-      to.om_chunk_off[NLV] = offom;
-      gto += 3 * offom;
     }
     c->last_kernel = c->cur_vfeat ? "k_conv0_feat" : "k_conv0_fused";
     {  // DIAGNOSTICS (-DSPS_DIAG): SPS_DIAG_CONV0 = 1: only the hosted order bodies run, 2: only the convolution
@@ -899,60 +822,6 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     }
   }
   const bool ds = cs.ds_cin > 0;
-  // 3x3x3x3 layers of the coarse levels in a compact context: offset-major pair-exact GEMM into the product buffer, then the
-  // per-row sum in ME's accumulation order + epilogue (om_kernels.inc.h)
-  if (cs.K == 81 && om_layer(c, cc.name, cc.level_out) && !cc.fin && !cc.up) {
-    const Level &L = c->lv[cc.level_out];
-    OmArgs o{};
-    o.in = cc.in, o.ldi = cc.ldi;
-    o.in2 = cc.in2, o.ldi2 = cc.ldi2;
-    o.Wu = a.Wu;
-    o.ome = L.om_e, o.seg = L.om_seg;
-    o.cnt = c->counts + OMC + OM_CSTRIDE * (cc.level_out - OM_FIRST_LEVEL);
-    o.n_out = a.n_out, o.abort_flag = a.abort_flag;
-    o.prod = c->om_prod;
-    o.ldn = c->capl[cc.level_out];
-    o.in_bytes = (uint32_t)((size_t)c->capl[cc.level_out] * (size_t)cc.ldi * 4u);
-    o.in2_bytes = (uint32_t)((size_t)c->capl[cc.level_out] * (size_t)(cc.ldi2 > 0 ? cc.ldi2 : 1) * 4u);
-    o.wu_bytes = (uint32_t)(cs.wu_numel() * 4);
-    o.ome_bytes = (uint32_t)(81 * (size_t)c->capl[cc.level_out] * 8u);
-    o.pcap = (int)L.om_pcap;
-    o.prod_bytes = (uint32_t)std::min<size_t>(c->om_prod_bytes, (size_t)(L.om_pcap + c->capl[cc.level_out]) * (size_t)cs.cout * 4u);
-    o.scale = a.scale, o.shift = a.shift, o.res = cc.res, o.ldr = cc.ldr;
-    o.out = cc.out, o.ldo = cc.ldo, o.relu = cc.relu, o.has_ds = ds ? 1 : 0;
-    if (ds && !cc.in2) return fail(SPS_ERR_INVALID, "%s needs the block input for its fused downsample", cc.name);
-    static const int om_grid = [] { const char *e = diag_env("SPS_OM_GRID"); return e ? atoi(e) : 768; }();  // DIAGNOSTICS
-    const dim3 g1((unsigned)om_grid);
-    const int lpr = cs.cout / 4;
-    int64_t g2 = (((c->cap >> cc.level_out) + 1) * lpr + 255) / 256;  // expected rows x threads per row (rows shrink ~2.5x per level)
-    if (g2 < 64) g2 = 64;
-    if (g2 > 4096) g2 = 4096;
-    c->last_kernel = "k_om_gemm+k_om_sum";
-    const int key = cs.cin * 10000 + cs.cout * 100 + cs.ds_cin;
-    static const int om_rt = [] { const char *e = diag_env("SPS_OM_RT"); return e ? atoi(e) : SPS_OM_RT; }();  // DIAGNOSTICS
-#define SPS_OM_LAUNCH(CIN_, COUT_, CIN2_)                                                                  \
-  do {                                                                                                     \
-    if (om_rt == 1)                                                                                        \
-      hipLaunchKernelGGL((k_om_gemm<CIN_, COUT_, 1, CIN2_, 4>), g1, dim3(256), 0, st, o);                  \
-    else                                                                                                   \
-      hipLaunchKernelGGL((k_om_gemm<CIN_, COUT_, 2, CIN2_, 4>), g1, dim3(256), 0, st, o);                  \
-    hipLaunchKernelGGL((k_om_sum<COUT_>), dim3((unsigned)g2), dim3(256), 0, st, o);                        \
-  } while (0)
-    switch (key) {
-      case 81600: SPS_OM_LAUNCH(8, 16, 0); return SPS_OK;     // block2.conv1
-      case 161608: SPS_OM_LAUNCH(16, 16, 8); return SPS_OK;   // block2.conv2
-      case 163200: SPS_OM_LAUNCH(16, 32, 0); return SPS_OK;   // block3.conv1
-      case 323216: SPS_OM_LAUNCH(32, 32, 16); return SPS_OK;  // block3.conv2
-      case 326400: SPS_OM_LAUNCH(32, 64, 0); return SPS_OK;   // block4.conv1
-      case 646432: SPS_OM_LAUNCH(64, 64, 32); return SPS_OK;  // block4.conv2
-      case 966400: SPS_OM_LAUNCH(96, 64, 0); return SPS_OK;   // block5.conv1
-      case 646496: SPS_OM_LAUNCH(64, 64, 96); return SPS_OK;  // block5.conv2
-      case 483200: SPS_OM_LAUNCH(48, 32, 0); return SPS_OK;   // block6.conv1
-      case 323248: SPS_OM_LAUNCH(32, 32, 48); return SPS_OK;  // block6.conv2
-      default: return fail(SPS_ERR_INVALID, "no offset-major instantiation for %s (%d -> %d, downsample %d)", cc.name, cs.cin, cs.cout, cs.ds_cin);
-    }
-#undef SPS_OM_LAUNCH
-  }
   // one-column-tile layers over a 3x3x3x3 map: pair-exact kernel over the level's rulebook (k_conv_px)
   if (cc.level_out < PX_LEVELS && ((px_levels() >> cc.level_out) & 1) && c->lv[cc.level_out].rb_e && cs.K == 81 && a.NT == 1 && (cs.cout == 8 || cs.cout == 16) &&
       (cs.cin == 8 || cs.cin == 16 || cs.cin == 24) && (!cc.fin || cs.cout == 8)) {
@@ -1531,15 +1400,15 @@ static int forward_impl(sps_ctx *c, const float *coords, int64_t ld, int64_t n, 
       {"conv4p8s2", c->cat5 + 64, 96, c->x4, 32, Map{lv[4].down, lv[4].tmdown}, 4, nullptr, 0, 1},
       {"block4.0.conv1", c->x4, 32, c->b4t, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1},
       {"block4.0.conv2", c->b4t, 64, c->b4o, 64, Map{lv[4].nbr3, lv[4].tm3}, 4, nullptr, 0, 1, c->x4, 32, false,
-       (FUSE_UP & 1) && !om_layer(c, "block4.0.conv2", 4) ? "convtr4p16s2" : nullptr, c->cat5, 96},
+       (FUSE_UP & 1) ? "convtr4p16s2" : nullptr, c->cat5, 96},
       {"convtr4p16s2", c->b4o, 64, c->cat5, 96, Map{lv[4].down, lv[4].tmdown}, 3, nullptr, 0, 1},
       {"block5.0.conv1", c->cat5, 96, c->b5t, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1},
       {"block5.0.conv2", c->b5t, 64, c->b5o, 64, Map{lv[3].nbr3, lv[3].tm3}, 3, nullptr, 0, 1, c->cat5, 96, false,
-       (FUSE_UP & 2) && !om_layer(c, "block5.0.conv2", 3) ? "convtr5p8s2" : nullptr, c->cat6, 48},
+       (FUSE_UP & 2) ? "convtr5p8s2" : nullptr, c->cat6, 48},
       {"convtr5p8s2", c->b5o, 64, c->cat6, 48, Map{lv[3].down, lv[3].tmdown}, 2, nullptr, 0, 1},
       {"block6.0.conv1", c->cat6, 48, c->b6t, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1},
       {"block6.0.conv2", c->b6t, 32, c->b6o, 32, Map{lv[2].nbr3, lv[2].tm3}, 2, nullptr, 0, 1, c->cat6, 48, false,
-       (FUSE_UP & 4) && !om_layer(c, "block6.0.conv2", 2) ? "convtr6p4s2" : nullptr, c->cat7, 24},
+       (FUSE_UP & 4) ? "convtr6p4s2" : nullptr, c->cat7, 24},
       {"convtr6p4s2", c->b6o, 32, c->cat7, 24, Map{lv[2].down, lv[2].tmdown}, 1, nullptr, 0, 1},
       {"block7.0.conv1", c->cat7, 24, c->b7t, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1},
       {"block7.0.conv2", c->b7t, 16, c->b7o, 16, Map{lv[1].nbr3, lv[1].tm3}, 1, nullptr, 0, 1, c->cat7, 24, false,
@@ -2143,7 +2012,7 @@ int sps_get_nbr(sps_ctx *c, int which, int32_t *nbr_dev) {
 }
 
 int sps_get_kernel_map(sps_ctx *c, int which, int source, int32_t *out_dev, int64_t *n_entries) {
-  if (!c || !out_dev || which < 0 || which > 9 || source < 0 || source > 2) return fail(SPS_ERR_INVALID, "bad arguments");
+  if (!c || !out_dev || which < 0 || which > 9 || source < 0 || source > 1) return fail(SPS_ERR_INVALID, "bad arguments");
   int64_t cnt[SPS_NUM_LEVELS];
   int rc = sps_level_counts(c, cnt);
   if (rc != SPS_OK) return rc;
@@ -2152,41 +2021,6 @@ int sps_get_kernel_map(sps_ctx *c, int which, int source, int32_t *out_dev, int6
   const int64_t n = cnt[level];
   if (n_entries) *n_entries = -1;
   if (n == 0) return SPS_OK;
-  if (source == 2) {
-    // the offset-major rulebook of a coarse level (compact contexts): decoded the way k_om_gemm / k_om_sum read it
-    if (which > 4 || !om_level(c, which)) return fail(SPS_ERR_INVALID, "map %d has no offset-major rulebook in this context", which);
-    const Level &L = c->lv[which];
-    const int *cntd = c->counts + OMC + OM_CSTRIDE * (which - OM_FIRST_LEVEL);
-    int h_cnt[OM_CSTRIDE];
-    HIP_TRY(hipMemcpy(h_cnt, cntd, sizeof h_cnt, hipMemcpyDeviceToHost));
-    int64_t total = 0;
-    for (int k = 0; k < 81; ++k) total += h_cnt[k];
-    if (total != h_cnt[81]) return fail(SPS_ERR_INVALID, "offset-major rulebook of level %d: %lld list entries, %d product slots", which, (long long)total, h_cnt[81]);
-    if (h_cnt[81] > L.om_pcap) return fail(SPS_ERR_INVALID, "offset-major rulebook of level %d overflowed its product buffer", which);
-    int *slot_k = nullptr, *slot_in = nullptr;
-    const size_t sb = (size_t)std::max(1, h_cnt[81]) * sizeof(int);
-    HIP_TRY(hipMalloc((void **)&slot_k, sb));
-    if (hipMalloc((void **)&slot_in, sb) != hipSuccess) {
-      (void)hipFree(slot_k);
-      return fail(SPS_ERR_NOMEM, "hipMalloc failed");
-    }
-    (void)hipMemset(slot_k, 0xFF, sb);
-    (void)hipMemset(slot_in, 0xFF, sb);
-    (void)hipMemset(out_dev, 0xFF, (size_t)K * n * sizeof(int));
-    (void)hipMemset(c->pairs, 0, 128 * sizeof(unsigned long long));
-    hipLaunchKernelGGL(k_export_om_claim, dim3(64, 81), dim3(256), 0, 0, L.om_e, c->capl[which], cntd, h_cnt[81], slot_k, slot_in, c->pairs);
-    hipLaunchKernelGGL(k_export_om_rows, dim3(grid_for(n, 256, 1024), 3), dim3(256), 0, 0, L.om_seg, c->capl[which], c->counts + which, cntd,
-                       slot_k, slot_in, out_dev, c->pairs);
-    unsigned long long h[2];
-    const hipError_t e1 = hipMemcpy(h, c->pairs, sizeof h, hipMemcpyDeviceToHost);
-    (void)hipFree(slot_k);
-    (void)hipFree(slot_in);
-    if (e1 != hipSuccess) return fail(SPS_ERR_HIP, "hipMemcpy failed: %s", hipGetErrorString(e1));
-    if (h[1]) return fail(SPS_ERR_INVALID, "offset-major rulebook of level %d: %llu malformed, duplicate or out-of-order entries", which, h[1]);
-    if ((int64_t)h[0] != total) return fail(SPS_ERR_INVALID, "offset-major rulebook of level %d: %llu of %lld pairs reachable from the rows' slot runs", which, h[0], (long long)total);
-    if (n_entries) *n_entries = (int64_t)h[0];
-    return SPS_OK;
-  }
   if (source == 1) {
     if (which > 4) return fail(SPS_ERR_INVALID, "only the 3x3x3x3 maps have a rulebook");
     const Level &L = c->lv[which];

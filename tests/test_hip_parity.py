@@ -96,11 +96,10 @@ def assert_same_pairs(got, want, perm_out, perm_in, what):
     np.testing.assert_array_equal(mapped, want[:, perm_out], err_msg=what)
 
 
-def check_kernel_maps(cm, perm, counts, om=False):
-    """Row a10 as pair SETS: the 3x3x3x3 map of every level from the neighbour table AND decoded from the rulebook the
-    convolutions read (levels 0-1: supertile rulebook; ``om``: levels 2-4 of a compact context: offset-major rulebook), the
-    5x5x5x1 map, and the four stride-2 maps (= the transposed convolutions' maps with in / out swapped) against
-    cm.k3 / k5 / kdown of the oracle."""
+def check_kernel_maps(cm, perm, counts):
+    """Row a10 as pair SETS: the 3x3x3x3 map of every level from the neighbour table AND (levels that run pair-exact) decoded
+    from the rulebook the convolutions read, the 5x5x5x1 map, and the four stride-2 maps (= the transposed convolutions' maps
+    with in / out swapped) against cm.k3 / k5 / kdown of the oracle."""
     c = ctx()
     n_pairs = 0
     for l in range(5):
@@ -110,10 +109,6 @@ def check_kernel_maps(cm, perm, counts, om=False):
             tab, n_entries = c.kernel_map(l, 1)
             assert n_entries == int((want >= 0).sum()), f"rulebook level {l}: {n_entries} pairs, oracle {(want >= 0).sum()}"
             assert_same_pairs(tab.cpu().numpy(), want, perm[l], perm[l], f"3^4 rulebook, level {l}")
-        elif om:
-            tab, n_entries = c.kernel_map(l, 2)
-            assert n_entries == int((want >= 0).sum()), f"offset-major rulebook level {l}: {n_entries} pairs, oracle {(want >= 0).sum()}"
-            assert_same_pairs(tab.cpu().numpy(), want, perm[l], perm[l], f"3^4 offset-major rulebook, level {l}")
         n_pairs += int((want >= 0).sum())
     assert_same_pairs(c.kernel_map(5, 0).cpu().numpy(), oracle_table(cm.k5(), counts[0]), perm[0], perm[0], "5x5x5x1 map")
     for l in range(1, 5):
@@ -123,10 +118,8 @@ def check_kernel_maps(cm, perm, counts, om=False):
     return n_pairs
 
 
-def check_full(net, params, batch, tol=2e-4, both_classes=False, om=False):
+def check_full(net, params, batch, tol=2e-4, both_classes=False):
     dev, scores = run(net, batch)
-    if om:
-        ctx().check_errors(torch.cuda.current_stream().cuda_stream)   # no product-buffer overflow (SPS_ERR_NOMEM)
     ref, info = O.sps_forward(params, batch[:, :5], VS, keep=True)
     counts = ctx().level_counts()
     cm = info["cm"]
@@ -148,7 +141,7 @@ def check_full(net, params, batch, tol=2e-4, both_classes=False, om=False):
         want = [len(i) for i, _ in cm.k3(1 << l)]
         assert ctx().map_pairs(l) == want, f"3^4 map level {l}"
     assert ctx().map_pairs(5) == [len(i) for i, _ in cm.k5()]
-    check_kernel_maps(cm, perm, counts, om)                       # ... and as pair sets, offset by offset
+    check_kernel_maps(cm, perm, counts)                           # ... and as pair sets, offset by offset
     # --- features
     tap_level = {"out_p1": 0, "block1": 1, "block2": 2, "block3": 3, "block4": 4, "block5": 3, "block6": 2,
                  "block7": 1, "block8": 0}
@@ -172,45 +165,6 @@ def check_full(net, params, batch, tol=2e-4, both_classes=False, om=False):
 
 def test_small_scene_full_parity(net, params):
     check_full(net, params, synthetic.small_scene(seed=0, n_scan=2000), both_classes=True)
-
-
-@pytest.fixture
-def compact_ctx():
-    """The default context with COMPACT arenas (what ScanEngine's contexts are): the 3x3x3x3 layers of levels 2-4 run the
-    offset-major pair-exact kernels (k_om_gemm + k_om_sum) instead of k_conv.  Fractions just below 1: nothing can overflow."""
-    c = ctx()
-    c.set_level_fractions([1.0, 0.999, 0.999, 0.999, 0.999])
-    yield c
-    c.set_level_fractions(None)
-
-
-def test_offset_major_small_scene_full_parity(net, params, compact_ctx):
-    """Same oracle comparison as above through the coarse levels' offset-major path: voxel sets, every kernel map incl. the
-    offset-major rulebooks as pair sets, block features, logits, scores, labels."""
-    check_full(net, params, synthetic.small_scene(seed=0, n_scan=2000), both_classes=True, om=True)
-    check_full(net, params, synthetic.small_scene(seed=5, n_scan=700), om=True)
-
-
-def test_offset_major_equals_output_stationary(net, params, compact_ctx):
-    """The two coarse-level paths against each other on one input: same sums in another order (block features to 1e-5)."""
-    batch = synthetic.small_scene(seed=21, n_scan=3000)
-    _, s_om = run(net, batch)
-    f_om = {n: get_feature(n) for n in ("block2", "block3", "block4", "block5", "block6")}
-    compact_ctx.set_level_fractions(None)
-    _, s_os = run(net, batch)
-    for n, want in f_om.items():
-        np.testing.assert_allclose(get_feature(n), want, rtol=1e-5, atol=1e-5, err_msg=n)
-    np.testing.assert_allclose(s_om.cpu().numpy(), s_os.cpu().numpy(), rtol=0, atol=2e-6)
-
-
-def test_offset_major_run_to_run_determinism(net, compact_ctx):
-    """The order of the waves inside the offset lists varies from run to run (atomics); no result depends on it."""
-    batch = synthetic.small_scene(seed=31, n_scan=4000)
-    _, s0 = run(net, batch)
-    s0 = s0.clone()
-    for _ in range(3):
-        _, s = run(net, batch)
-        assert torch.equal(s, s0)
 
 
 def test_other_seed_and_default_bn(params):
@@ -421,20 +375,6 @@ def test_config2_full_size_parity(net, params):
     """BASELINE config 2 (~100k-pt scan + submap, 0.1 m): full oracle comparison."""
     sc = synthetic.make_scene(scan_seed=1)
     check_full(net, params, sc["batch"], tol=5e-4, both_classes=True)
-
-
-@pytest.mark.timeout(600)
-def test_config2_full_size_parity_offset_major(net, params):
-    """BASELINE config 2 with the product loop's arenas (ScanEngine: LiDAR level fractions): the coarse levels run
-    offset-major; full oracle comparison incl. the offset-major rulebooks as pair sets."""
-    from sps_amd._native import Context
-    sc = synthetic.make_scene(scan_seed=1)
-    c = ctx()
-    c.set_level_fractions(Context.LIDAR_FRACTIONS)
-    try:
-        check_full(net, params, sc["batch"], tol=5e-4, both_classes=True, om=True)
-    finally:
-        c.set_level_fractions(None)
 
 
 def test_lightning_checkpoint_roundtrip(tmp_path, params):
