@@ -101,6 +101,29 @@ def morton_sorted(batch, vs):
     return np.ascontiguousarray(batch[np.argsort(key, kind="stable")])
 
 
+def cpu_quota():
+    """CPUs this job may use: the smallest of the host's cores, the process's affinity mask and the cgroup CPU quota
+    (cgroup v2 cpu.max, v1 cfs_quota_us / cfs_period_us); the CPU baseline's thread sweep stops there."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(round(int(q) / int(p)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(round(q / p))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sps_amd", "csrc")
@@ -158,7 +181,7 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-buffer-fed timed region: `value` is then the "
                     "resident-input rate (diagnostic runs; the headline includes the copy, SURVEY 8(d))")
     ap.add_argument("--no-stages", action="store_true", help="skip the per-layer hipEvent pass")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target wall time of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="target wall time of the CPU baseline sample")
     ap.add_argument("--order", default="scan", choices=["scan", "morton"],
                     help="DIAGNOSTIC: row order of the synthetic batches -- 'scan' = as a LiDAR delivers them (ring by ring; "
                          "the default and the headline), 'morton' = rows pre-sorted by the Z-order of their voxel (probes how "
@@ -380,6 +403,20 @@ def main():
         "dominant_kernel": dom, "largest_traffic_kernel": dom_bytes if stages else None,
         "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
     }
+    # rocprofv3 kernel durations of the same build (tools/kernel_durations.py, written by tools/collect_evidence.sh): the
+    # launches of one forward in order, mapped onto the stages -- kernel time without the launch gaps the hipEvent stages hold
+    rocprof_us = {}
+    kp = os.path.join(ROOT, "profiles", "kernel_durations.json")
+    if classes and os.path.exists(kp) and args.config == 2:
+        kj = json.load(open(kp))
+        seq = [s for s in stages if s["kernel"] != "(memset)"]
+        n_launch = sum(len(s["kernel"].split("+")) for s in seq)
+        if kj.get("csrc_sha") == csrc_sha() and len(kj["launches"]) == n_launch:
+            i = 0
+            for s in seq:
+                k = len(s["kernel"].split("+"))
+                rocprof_us[s["kernel"]] = rocprof_us.get(s["kernel"], 0.0) + sum(u for _, u in kj["launches"][i:i + k])
+                i += k
     if classes:
         # flat scalars (nested values do not survive the driver's parser): the kernel CLASS with the most time per step in the
         # serial pass (hipEvents around every launch), with its own roofline fractions
@@ -391,6 +428,12 @@ def main():
             dominant_kernel_alg_bytes=dv["bytes"], dominant_kernel_alg_flops=dv["flops"],
             dominant_kernel_hbm_frac=round(dv["bytes"] / t / 1e9 / roofline.HBM_PEAK_GBS, 5) if dv["bytes"] else None,
             dominant_kernel_mfma_frac=round(dv["flops"] / t / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5) if dv["flops"] else None,
+            # the same class / the whole forward as rocprofv3 sees them (kernel durations only; null unless
+            # profiles/kernel_durations.json was taken with this build): dominant_kernel_us above holds the launch gaps too
+            dominant_kernel_rocprof_us=round(rocprof_us[dk], 2) if dk in rocprof_us else None,
+            dominant_kernel_rocprof_mfma_frac=(round(dv["flops"] / (rocprof_us[dk] * 1e-6) / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5)
+                                               if dk in rocprof_us and dv["flops"] else None),
+            serial_kernel_rocprof_us_per_step=round(sum(rocprof_us.values()), 2) if rocprof_us else None,
             serial_kernel_us_per_step=round(sum(v["us"] for v in classes.values()), 2),
             launches_per_step=sum(v["launches"] for v in classes.values()),
             kernel_classes="; ".join(f"{k}: {v['us']:.1f} us / {v['launches']} launches"
@@ -406,13 +449,15 @@ def main():
               if "num_batches_tracked" not in k}
         blob = c_oracle.pack_blob(sd)
         host_cores = os.cpu_count() or 1
+        quota = cpu_quota()                                       # what this JOB may use (cgroup quota / affinity), not the host's cores
         batch_np = batches_np[(K - 1) % len(batches_np)]          # the batch of the last timed step
         coords = np.ascontiguousarray(batch_np[:, :5])
         # the port runs tile by tile of output rows (round 4; the per-offset loops of rounds 1-3 stopped scaling at 16
         # threads); the serial voxel hash (first-occurrence order) bounds it: take the best of a few thread counts (one pass
         # each) and report the count actually used as `cores`
         best, single = None, None
-        for th in sorted({t for t in (1, 4, 8, 16, 32, 64, 128, 256) if t <= host_cores}):
+        sweep = sorted({t for t in (1, 4, 8, 16, 32, 64) if t < quota} | {quota})
+        for th in sweep:
             if args.config != 2 and th == 1:
                 continue
             c_oracle.forward(blob, coords, vs, nthreads=th, want_details=False)
@@ -432,7 +477,8 @@ def main():
         cpu = {"value": round(nb / per, 3), "unit": "scans/s", "cores": cores, "kind": "port",
                "sample": f"{nrep} repeats of one step's batch ({len(batch_np)} rows, {nb} scan(s)) through the C restatement of "
                          f"the MinkowskiEngine algorithm (ME itself unavailable), OpenMP over tiles of output rows with {cores} "
-                         f"threads = the fastest of 1/4/8/16/32/64/128/256 on this {host_cores}-core host",
+                         f"threads = the fastest of {'/'.join(map(str, sweep))} (the job's CPU quota: {quota} of the host's {host_cores} cores)",
+               "cpu_quota": quota,
                "single_thread_scans_per_s": round(nb / single, 3) if single else None}
         s = scores.cpu().numpy()
         e = np.float32(eps)

@@ -71,9 +71,13 @@ def batched(loader, k):
 @click.option("--streams", type=int, default=None, help="forwards in flight (HIP streams); default: the engine's")
 @click.option("--timing", is_flag=True, help="print scans/s of the evaluation loop (rank 0)")
 @click.option("--force-dist", is_flag=True, help="initialise the process group (RCCL) and all-gather the metric rows even at world size 1")
+@click.option("--backend", type=str, default=None,
+              help="torch.distributed backend (default: $SPS_DIST_BACKEND, else nccl = RCCL over xGMI).  gloo lets several ranks "
+                   "share ONE GPU (rank -> device LOCAL_RANK mod device count): how the sharding and the padded metric "
+                   "all-gather are tested on a one-GPU box")
 @click.option("--host-items", is_flag=True, help="assemble the items on the host (DataLoader workers + scipy cKDTree, as the "
                                                  "reference does) instead of on the device")
-def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams, timing, force_dist, host_items):
+def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams, timing, force_dist, backend, host_items):
     cfg = yaml.safe_load(open(config))
     if me_conventions:
         cfg["MODEL"]["ME_CONVENTIONS"] = me_conventions
@@ -86,6 +90,9 @@ def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams
 
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = backend or os.environ.get("SPS_DIST_BACKEND", "nccl")
+    if backend != "nccl":                          # ranks may share a GPU (RCCL wants one device per rank)
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     from sps_amd import hostplace
@@ -94,7 +101,10 @@ def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     raw_scans = None
     if n_synth:

@@ -247,6 +247,29 @@ def test_predict_cli_pipelined_matches_bench_loop():
     assert outs[0] == outs[1]
 
 
+@pytest.mark.timeout(900)
+def test_predict_cli_two_ranks_on_one_gpu_gloo():
+    """BASELINE config 5's entry point with W > 1: scripts/predict.py under torch.distributed.run with two ranks sharing
+    the one GPU of this box (--backend gloo).  Group g -> rank g mod W, the per-scan index bookkeeping, the padded metric
+    all-gather (7 scans: rank 0 owns 4, rank 1 owns 3) and rank 0's mean of per-scan metrics (predict.py:80-83) must print
+    the same six lines as the one-rank run -- at batch 1 and at batch 2 (4 groups, the last one short)."""
+    base = [os.path.join("scripts", "predict.py"), "--synthetic", "7", "-c", os.path.join("config", "config.yaml"), "--streams", "3"]
+
+    def six(stdout):
+        lines = {l.split(" ")[0]: l for l in stdout.splitlines()}
+        return [lines[k] for k in ("Loss", "R2", "dIoU", "Precision", "Recall", "F1")]
+
+    for port, bs in ((29551, "1"), (29552, "2")):
+        one = _run([sys.executable] + base + ["-b", bs])
+        assert one.returncode == 0, one.stderr[-3000:]
+        two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                    "--master-port", str(port)] + base + ["-b", bs, "--backend", "gloo", "--timing"])
+        assert two.returncode == 0, two.stderr[-3000:]
+        assert two.stdout.count("########## Inference Metrics ##########") == 1          # rank 0 only
+        assert six(two.stdout) == six(one.stdout), (bs, two.stdout, one.stdout)
+        assert "timing: 7 scans" in two.stdout and "(2 GPU(s)" in two.stdout, two.stdout
+
+
 def test_compact_arena_overflow_aborts_reports_and_recovers(net, params):
     """sps_ctx_set_level_fractions: LiDAR-sized level arrays.  A LiDAR-like cloud runs unchanged in a third of the memory;
     a cloud whose coarse levels do not thin out (every point its own voxel at every stride) makes its forward abort on the

@@ -19,12 +19,16 @@ if python3 tools/traffic_pmc.py $o/pmc_FETCH_SIZE $o/pmc_WRITE_SIZE $o/traffic.j
 else
   echo "traffic_pmc.py failed: profiles/traffic.json left as it was" | tee -a $o/bench.err
 fi
+# rocprofv3 kernel durations of this build first: the bench lines below then carry `dominant_kernel_rocprof_us`
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_serial -- python3 bench.py --streams 1 --steps 80 --warmup 10 --no-cpu-baseline --no-h2d > $o/bench_under_rocprof_serial.json 2>> $o/bench.err
+if python3 tools/kernel_durations.py $o/prof_serial $o/kernel_durations.json >> $o/traffic_summary.txt 2>> $o/bench.err && [ -s $o/kernel_durations.json ]; then
+  cp $o/kernel_durations.json profiles/kernel_durations.json
+fi
 python3 bench.py > $o/bench.json 2>> $o/bench.err
 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $o/bench_driver_protocol.json 2>> $o/bench.err
 python3 bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline > $o/bench_serial_1stream.json 2>> $o/bench.err
 python3 bench.py --config 3 --steps 150 --warmup 20 > $o/bench_config3.json 2>> $o/bench.err
 python3 bench.py --config 4 --steps 150 --warmup 20 > $o/bench_config4.json 2>> $o/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_serial -- python3 bench.py --streams 1 --steps 80 --warmup 10 --no-cpu-baseline --no-h2d > $o/bench_under_rocprof_serial.json 2>> $o/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_pipelined -- python3 bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-stages --no-h2d > $o/bench_under_rocprof_pipelined.json 2>> $o/bench.err
 cp $(ls $o/prof_serial/*/*kernel_stats.csv | head -1) $o/kernel_stats.csv
 cp $(ls $o/prof_pipelined/*/*kernel_stats.csv | head -1) $o/kernel_stats_pipelined.csv
