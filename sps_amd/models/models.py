@@ -403,7 +403,8 @@ class SPSNet(nn.Module):
         # means are taken over the rows with t == 1 on the device, so the step never waits for the GPU (no index list, no
         # size to learn) -- in the library's two launches when the batch is a plain float32 matrix on the GPU
         if (scores.is_cuda and batch.is_cuda and batch.dtype == torch.float32 and batch.dim() == 2 and batch.shape[1] >= 6
-                and batch.stride(1) == 1 and scores.dtype == torch.float32 and scores.is_contiguous()):
+                and batch.stride(1) == 1 and scores.dtype == torch.float32 and scores.is_contiguous()
+                and scores.shape[0] > 0):     # (an empty batch takes the torch formulation below: NaN loss, as the reference's)
             return _ScanMSE.apply(scores, batch)
         w = (coordinates[:, 4] == 1).to(scores.dtype)
         cnt = w.sum()

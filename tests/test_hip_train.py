@@ -342,5 +342,44 @@ def test_scan_mse_equals_the_torch_formulation_of_common_step():
     none[:, 4] = 0
     loss, _ = _ScanMSE.apply(torch.rand(n).cuda(), none.cuda())
     assert torch.isnan(loss)
-    # and common_step takes this path (same numbers as its torch fallback on a float64 batch view)
     assert SPSNet.common_step.__code__.co_names.count("_ScanMSE") == 1
+
+
+def test_common_step_dispatch_native_loss_equals_the_torch_fallback():
+    """common_step itself (models.py:62-70) on both of its paths: a float32 row-major CUDA batch goes through the library's
+    loss (sps_scan_mse), a batch with a column stride (a transposed view) through the torch formulation -- same loss, same
+    R2, same gradients of the network's parameters; an EMPTY validation batch takes the fallback and yields NaN instead of failing."""
+    params = O.random_params(seed=0)
+    batch = synthetic.small_scene(seed=13, n_scan=800)
+    taken = []
+    from sps_amd.models import models as M
+    orig = M._ScanMSE.apply
+
+    def spy(*a):
+        taken.append(True)
+        return orig(*a)
+
+    res = []
+    for strided in (False, True):
+        net = net_from_params(params).cuda().train()
+        dev = torch.from_numpy(batch).cuda()
+        if strided:
+            dev = dev.t().contiguous().t()                      # same values, stride(1) != 1: the torch fallback
+            assert dev.stride(1) != 1
+        taken.clear()
+        M._ScanMSE.apply = spy
+        try:
+            loss, r2 = net.common_step(dev)
+        finally:
+            M._ScanMSE.apply = orig
+        assert bool(taken) == (not strided)
+        loss.backward()
+        torch.cuda.synchronize()
+        res.append((float(loss), float(r2), {k: p.grad.detach().cpu().numpy() for k, p in net.named_parameters()}))
+    (l0, r0, g0), (l1, r1, g1) = res
+    assert l0 == pytest.approx(l1, rel=1e-5) and r0 == pytest.approx(r1, rel=1e-4, abs=1e-5)
+    for k in g0:
+        assert rel_err(g0[k], g1[k]) < 1e-4, k
+    net = net_from_params(params).cuda().eval()                 # (validation_step; a TRAINING step refuses an empty batch)
+    loss, _ = net.common_step(torch.zeros((0, 6), dtype=torch.float32, device="cuda"))
+    assert torch.isnan(loss)

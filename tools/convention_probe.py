@@ -29,10 +29,22 @@ from sps_amd.models.models import SPSNet  # noqa: E402
 def probe(state_dict: dict, cfg: dict, batch: torch.Tensor, combos=None):
     """[(conventions, metrics dict)] sorted by R2 (NaN last), best first.  ``batch`` is a device tensor [N, 6]."""
     net = SPSNet(cfg)
-    net.load_state_dict(state_dict)
+    combos = list(combos or CV.all_combinations())
+    try:
+        net.load_state_dict(state_dict)
+    except RuntimeError as e:
+        # a non-square 1x1 kernel stored [C_out, C_in] fails the strict load under the default reading (the load hook only
+        # accepts that shape once lin_layout = out_in is declared): load under out_in and probe that half of the combinations
+        if "size mismatch" not in str(e):
+            raise
+        net = SPSNet(cfg)
+        net.model.set_me_conventions(CV.parse("lin_layout=out_in"))
+        net.load_state_dict(state_dict)
+        combos = [cv for cv in combos if cv.lin_layout == "out_in"]
+        print("the checkpoint's 1x1 kernels are stored [C_out, C_in]: probing the lin_layout = out_in combinations only", file=sys.stderr)
     net = net.cuda().eval().freeze()
     out = []
-    for cv in (combos or CV.all_combinations()):
+    for cv in combos:
         net.model.set_me_conventions(cv)
         net.predict_loss.clear()
         m = net.predict_step(batch, 0)
