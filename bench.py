@@ -166,12 +166,12 @@ def main():
     ap.add_argument("--azimuth", type=int, default=1750, help="azimuth steps of the synthetic LiDAR (1750 -> ~100k pts)")
     ap.add_argument("--seq-scans", type=int, default=32, help="config 3: distinct scans of the sequence (cycled)")
     ap.add_argument("--scenes", type=int, default=4, help="config 2: distinct scans cycled through the steps")
-    ap.add_argument("--streams", type=int, default=7,
-                    help="independent steps in flight per GPU (one HIP stream + native context each); 1 = strictly serial. "
-                         "Default 7 = the knee of the stream sweep (DESIGN.md section 3.2: 3 streams reach 96 %% of the best "
-                         "rate, 7 reach 99 %%, 23 cost 3x the arena memory for +1 %%).  Short runs use fewer so that every stream "
-                         "executes about three timed steps.  The HIP runtime multiplexes streams onto 4 hardware queues: counts "
-                         "of the form 4k+3 measure 5-15 %% above their neighbours")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="independent steps in flight per GPU (one HIP stream + native context each, the current stream being "
+                         "one of them); 1 = strictly serial.  The HIP runtime deals a process's streams to 4 hardware queues: "
+                         "pipeline counts that are multiples of 4 load the queues evenly (DESIGN.md section 3.2).  Default 8; "
+                         "runs of fewer than 40 steps use 4 so that every pipeline executes several timed steps")
+    ap.add_argument("--side-streams-only", action="store_true", help="DIAGNOSTIC: the current stream is NOT one of the --streams pipelines (round 4's engine)")
     ap.add_argument("--exact-streams", action="store_true", help="DIAGNOSTIC: use exactly --streams streams even for short runs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank control flow on a single GPU)")
@@ -243,12 +243,14 @@ def main():
             net.model.mark_weights_dirty()
 
     # ---- engine: arena + shared weights + one forward per context, all before the timed region -------------------
-    # every stream should execute ~3 timed steps (a run of K steps on K streams measures the fill + drain of K one-step
-    # pipelines): K = 20 -> 7 streams, K < 18 -> 3
+    # every pipeline should execute several timed steps (a run of K steps on K streams measures the fill + drain of K
+    # one-step pipelines): K < 5 x the default 8 pipelines -> 4 (one per hardware queue), K < 8 -> 2
     S = max(1, min(args.streams, K))
-    if S > 3 and K < 2.5 * S and not args.exact_streams:
-        S = 7 if (args.streams >= 7 and K >= 18) else 3
-    eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb, stage_cols=0 if args.no_h2d else 6)
+    if S > 2 and K < 5 * S and not args.exact_streams:
+        from sps_amd.engine import SHORT_RUN_STREAMS
+        S = SHORT_RUN_STREAMS if (args.streams >= SHORT_RUN_STREAMS and K >= 2 * SHORT_RUN_STREAMS) else 2
+    eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb, stage_cols=0 if args.no_h2d else 6,
+                     include_main=not args.side_streams_only)
     streams = eng.streams
     main_stream = eng.main
 
@@ -327,8 +329,10 @@ def main():
     confusion = {k: float(np.mean([m[k] for m in per_scan])) for k in ("tp", "fp", "fn", "tn")}
 
     # ---- roofline: algorithmic bytes of THIS run / GPU time per step --------------------------
-    ctx = eng.ctxs[0]
-    with torch.cuda.stream(streams[0]):
+    # (the engine's LAST pipeline: a side stream whose shared per-stream context the engine uses -- the pipeline on the
+    #  current stream runs on a private context -- so that net(...) on that stream and the introspection meet the same one)
+    ctx = eng.ctxs[-1]
+    with torch.cuda.stream(streams[-1]):
         net(batches[0])
     torch.cuda.synchronize()
     V = ctx.level_counts()
@@ -343,7 +347,7 @@ def main():
         ctx.profile_enable(True)
         acc, reps, order = {}, 10, []
         for _ in range(reps):
-            with torch.cuda.stream(streams[0]):
+            with torch.cuda.stream(streams[-1]):
                 net(batches[0])
             for name, ms in ctx.profile_read():
                 if name not in acc:
@@ -509,7 +513,7 @@ def main():
                    "scan_points": n_scan, "rows": n_points, "voxels_per_level": V,
                    "pairs_3x3x3x3_per_level": pairs3, "pairs_5x5x5x1": pairs5, "sharding": f"dp{world}",
                    "streams_per_gpu": S, "final_bias_calibrated": float(bias.item()),
-                   "arena_mb_per_context": round(eng.ctxs[0].arena_bytes() / 2**20, 1),
+                   "arena_mb_per_context": round(eng.ctxs[-1].arena_bytes() / 2**20, 1),
                    "arena_mb_all_contexts": round(sum(cx.arena_bytes() for cx in eng.ctxs) / 2**20, 1),
                    "compact_arenas": eng.compact},
         "roofline": roof, "cpu_baseline": cpu, "parity": parity, "mean_metrics": mean_metrics,

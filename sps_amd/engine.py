@@ -20,12 +20,20 @@ import torch
 
 from .models.models import SPSNet, _require_device_tensor, get_context, metrics_from_sums
 
-DEFAULT_STREAMS = 7       # knee of the stream sweep; the runtime multiplexes streams onto 4 hardware queues: 4k+3 maps best
+# Pipelines (HIP streams) per engine.  The runtime deals the streams of a process to 4 hardware queues in creation order, the
+# caller's current stream included, and a forward is as fast as its queue is free: the pipelines are spread evenly when their
+# number, WITH the current stream as one of them (include_main), is a multiple of 4.  Round 5, one box, 400 steps: 8 pipelines
+# incl. the current stream 4 340-4 357 scans/s host-fed (resident 4 367-4 381) against 4 158-4 191 (4 261-4 290) for round 4's
+# 7 side streams; 4 incl. the current stream are the best SHORT pipeline (20 steps: 3 887-3 945 against 3 757-3 824), but
+# leave a queue idle during a pipeline's host -> device copy (400 steps host-fed: 4 110); 8 side streams WITHOUT the current
+# one: 3 929 (profiles/round5_a/streams_queues.txt)
+DEFAULT_STREAMS = 8
+SHORT_RUN_STREAMS = 4
 
 
 class ScanEngine:
     def __init__(self, net: SPSNet, device: torch.device | int | None = None, streams: int = DEFAULT_STREAMS,
-                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0, compact: bool = True):
+                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0, compact: bool = True, include_main: bool = True):
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
@@ -36,8 +44,15 @@ class ScanEngine:
         S = max(1, int(streams))
         with torch.cuda.device(self.device):
             self.main = torch.cuda.current_stream()
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(S)] if S > 1 else [self.main]
-            self.ctxs = [get_context(self.index, st.cuda_stream) for st in self.streams]
+            if S > 1 and include_main:        # the caller's current stream carries one of the S pipelines
+                self.streams = [self.main] + [torch.cuda.Stream(device=self.device) for _ in range(S - 1)]
+            else:
+                self.streams = [torch.cuda.Stream(device=self.device) for _ in range(S)] if S > 1 else [self.main]
+            # the current stream's pipeline gets a context of ITS OWN: the shared per-stream context of that stream
+            # (get_context) belongs to whoever calls the model directly there and must not become compact / inference-only
+            from ._native import Context
+            self.ctxs = [Context(self.index) if (st is self.main and S > 1) else get_context(self.index, st.cuda_stream)
+                         for st in self.streams]
         # LiDAR-sized arenas (2.2 KB instead of 6.9 KB of device memory per point and context): a cloud whose coarse
         # levels do not thin out like a LiDAR scan's aborts its forward on the device; finish() then raises SpsError
         # (SPS_ERR_NOMEM) with the contexts already switched to full-size arenas, and run_sequence() re-runs once
@@ -84,7 +99,7 @@ class ScanEngine:
                 if cx.weights is not w:
                     cx.set_weights(w)
                 with torch.cuda.stream(st):
-                    self.net.forward_metrics(warm, 1, out)
+                    self.net.forward_metrics(warm, 1, out, ctx=cx)
             if table_rows:
                 self.reset_table(table_rows)
             if stage_cols and max_rows:
@@ -135,7 +150,7 @@ class ScanEngine:
             host_fed = not batch.is_cuda
             if host_fed:
                 batch = self._to_device(k, batch)
-            scores, _ = self.net.forward_metrics(batch, n_batches, self.table[row: row + n_batches])
+            scores, _ = self.net.forward_metrics(batch, n_batches, self.table[row: row + n_batches], ctx=self.ctxs[k])
             if host_fed:
                 # an event behind the forward as well (measured: without it the host-fed loop runs 14 % slower, 3 170 vs
                 # 3 678 scans/s at 7 streams -- the marker makes the runtime hand the stream's pending copy + kernels to

@@ -432,10 +432,11 @@ class SPSNet(nn.Module):
 
     @torch.no_grad()
     def forward_metrics(self, batch: torch.Tensor, n_batches: int = 1, out: torch.Tensor | None = None,
-                        scores: torch.Tensor | None = None):
+                        scores: torch.Tensor | None = None, ctx=None):
         """forward + the per-batch-index metric sums of predict_step in ONE native call (sps_forward_metrics): returns
         (scores [N], sums float64 [n_batches, 8] on the device).  ``batch`` rows are (b,x,y,z,t,label); ``out`` may be
-        a preallocated contiguous float64 device tensor of n_batches * 8 elements (e.g. a row of a results table)."""
+        a preallocated contiguous float64 device tensor of n_batches * 8 elements (e.g. a row of a results table);
+        ``ctx``: the native context to run on (default: the shared context of the current stream)."""
         _require_device_tensor(batch, "batch")
         if batch.dim() != 2 or batch.shape[1] < 6:
             raise ValueError(f"batch must be [N, 6] = (b,x,y,z,t,label), got {tuple(batch.shape)}")
@@ -443,7 +444,8 @@ class SPSNet(nn.Module):
             batch = batch.to(torch.float32).contiguous()
         with torch.cuda.device(batch.device):
             stream = torch.cuda.current_stream().cuda_stream
-            ctx = get_context(batch.device.index or 0, stream)
+            if ctx is None:
+                ctx = get_context(batch.device.index or 0, stream)
             self.model._sync_weights(ctx)
             n = batch.shape[0]
             if scores is None:

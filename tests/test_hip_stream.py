@@ -226,8 +226,8 @@ def test_bench_driver_protocol_is_steady_state():
                   "--no-h2d"])
         assert r.returncode == 0, r.stderr[-3000:]
         out[k] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert out[20]["config"]["streams_per_gpu"] == 7            # ~3 timed steps per stream, not 20 one-step pipelines
-    assert out[200]["config"]["streams_per_gpu"] == 7 and out[200]["config"]["arena_mb_all_contexts"] < 3072
+    assert out[20]["config"]["streams_per_gpu"] == 4            # five timed steps per pipeline, not 20 one-step pipelines
+    assert out[200]["config"]["streams_per_gpu"] == 8 and out[200]["config"]["arena_mb_all_contexts"] < 3072
     assert out[20]["value"] > 0.75 * out[200]["value"], (out[20]["value"], out[200]["value"])
     assert out[20]["mean_metrics"]["dIoU"] > 0
 
