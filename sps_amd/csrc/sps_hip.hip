@@ -1992,6 +1992,8 @@ int sps_get_tile_masks(sps_ctx *c, int which, uint32_t *masks_dev, int64_t *n_ti
   if (rc != SPS_OK) return rc;
   const int level = which == 5 ? 0 : which;
   *n_tiles = (cnt[level] + 15) / 16;
+  if (which <= 4 && !c->lv[which].nbr3)
+    return fail(SPS_ERR_INVALID, "an inference-only context keeps neither neighbour table nor tile masks at level %d", which);
   const uint32_t *src = which == 5 ? c->tm5 : c->lv[which].tm3;
   if (masks_dev && *n_tiles > 0)
     HIP_TRY(hipMemcpy(masks_dev, src, (size_t)*n_tiles * 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
