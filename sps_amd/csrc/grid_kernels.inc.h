@@ -103,9 +103,13 @@ __device__ inline int wave_run_insert(const BHash &h, uint64_t key, bool ok, uin
   }
   int slot = -1;
   if (head && ok) {
-    slot = bhash_insert(h, key);
-    atomicOr(&h.mask[slot], ((unsigned long long)ohi << 32) | olo);
-    atomicMin(&h.first[slot], src);  // the head is the run's smallest source index
+    if constexpr (SPS_ABLATE_FE & 1) {  // DIAGNOSTIC (wrong results): no atomics -- the slot is the key's home slot
+      slot = (int)(bhash32(key) >> h.hshift);
+    } else {
+      slot = bhash_insert(h, key);
+      atomicOr(&h.mask[slot], ((unsigned long long)ohi << 32) | olo);
+      atomicMin(&h.first[slot], src);  // the head is the run's smallest source index
+    }
   }
   return __shfl(slot, head_lane, 64);
 }
@@ -214,6 +218,7 @@ __device__ inline unsigned long long agg_pack(uint32_t gen, int t0, int t1) {
 }
 constexpr int SCAN_SPIN_MAX = 1 << 22;  // (seconds; a wait that long means a broken invariant: flag it instead of hanging the GPU)
 __device__ inline int2 scan_lookback(const unsigned long long *agg, int id, uint32_t gen, int *lds, int *err) {
+  if constexpr (SPS_ABLATE_FE & 2) return make_int2(0, 0);  // DIAGNOSTIC (wrong results): nobody waits for its predecessors
   int p0 = 0, p1 = 0;
   for (int i = threadIdx.x; i < id; i += SCAN_BLOCK) {
     unsigned long long v = __hip_atomic_load(agg + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -411,7 +416,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_rank_points(PyramidArgs a, int n
       }
     }
     const int r = k.wg_rank0 + j;
-    const int sl = wave_run_insert(a.h[l], pkey, ok, (uint32_t)pm, (uint32_t)(pm >> 32), r);
+    int sl = 0;
+    if constexpr (!(SPS_ABLATE_FE & 4))  // (ablation bit 2: the ancestors are not inserted)
+      sl = wave_run_insert(a.h[l], pkey, ok, (uint32_t)pm, (uint32_t)(pm >> 32), r);
     if (ok) a.sslot[l][r] = sl;
   }
 #if defined(SPS_FE_TRACE)
@@ -584,7 +591,7 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
       const int dx = j - 1;  // compile-time
       const bool self = dx == 0 && g == 13;
       res[j] = self ? r : -1;
-      probe[j] = gok && !self && kx + dx >= 0 && kx + dx < lim;
+      probe[j] = !(SPS_ABLATE_FE & 8) && gok && !self && kx + dx >= 0 && kx + dx < lim;  // (ablation bit 3: no probe touches the hash)
       nk[j] = gkey + (uint64_t)(int64_t)dx;
       sl[j] = (ghash + (uint32_t)dx * BH_X) >> h.hshift;
     }
@@ -618,8 +625,12 @@ __global__ __launch_bounds__(256) void k_link_adj(PyramidArgs a, int gb, int c1,
       }
     }
     int *__restrict__ o = badj + (size_t)r * 81 + g * 3;
+    if constexpr (SPS_ABLATE_FE & 16) {  // DIAGNOSTIC (wrong results): the entries are computed, not stored (except the block's own)
+      if (g == 13) o[1] = res[1];
+    } else {
 #pragma unroll
-    for (int j = 0; j < LINK_PER; ++j) o[j] = res[j];
+      for (int j = 0; j < LINK_PER; ++j) o[j] = res[j];
+    }
   }
 }
 

@@ -164,13 +164,14 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       const int e = (((c & 4) ? sz : 0) + 1) * 9 + (((c & 2) ? sy : 0) + 1) * 3 + (((c & 1) ? sx : 0) + 1);
       // (c = 0 in slice 1 is the block itself, entry 40 of its row: read like the others -- a branch around one load
       // would make the compiler drain the queue before the loads behind it)
-      const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsAdj, need ? adj4 + (uint32_t)e * 4u : OOR, 0, 0);
-      nbv[c] = need ? v : -1;
+      const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(rsAdj, (need && !(SPS_ABLATE_FE & 32)) ? adj4 + (uint32_t)e * 4u : OOR, 0, 0);
+      nbv[c] = need ? v : -1;  // (ablation bit 5: out-of-range loads -- no access, block 0 everywhere)
     }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsBmb, nbv[c] >= 0 ? (uint32_t)nbv[c] * 16u : OOR, 0, 0);
+      const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(rsBmb, (nbv[c] >= 0 && !(SPS_ABLATE_FE & 32)) ? (uint32_t)nbv[c] * 16u : OOR, 0, 0);
       mlo[c] = q.x, mhi[c] = q.y, bs[c] = (int)q.z;
+      if constexpr (SPS_ABLATE_FE & 32) mlo[c] = 0x0F0F0F0Fu & (uint32_t)(nbv[c] + 1), mhi[c] = mlo[c];  // (some neighbours, no memory)
     }
     uint32_t m = 0u;
     int cb = 0;  // chunks written to the segment so far
@@ -180,7 +181,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
     // (all 27 offsets unrolled: 125 VGPRs + spilled SGPRs, 29 us instead of 22.  Measured and dropped as well: 32-bit halves of
     //  the masks + the per-tile bits kept in scalar registers -- fewer VALU instructions, 98 VGPRs, 27 us)
 #pragma unroll 1
-    for (int dz = -1; dz <= 1; ++dz) {
+    for (int dz = -1; dz <= ((SPS_ABLATE_FE & 128) ? -2 : 1); ++dz) {  // (ablation bit 7: no offset is walked)
       const int tz = pz + dz;
       const bool oz = (tz >> 2) != 0;
       uint32_t zlo[4], zhi[4];
@@ -210,7 +211,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
           if (want_tm) {  // wave-uniform
             const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
             // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
-            if (any && ok && nbr) nbr[(size_t)(27 * slice + j) * ldn + u] = row;
+            if (any && ok && nbr && !(SPS_ABLATE_FE & 64)) nbr[(size_t)(27 * slice + j) * ldn + u] = row;  // (ablation bit 6: no stores)
             m |= any ? 1u << j : 0u;
           }
           if (eb) {  // wave-uniform
@@ -218,7 +219,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
             // without one write the padding behind the entries (there are always enough: cnt > 48 => 64 - cnt = the padding)
             const int cnt = __popcll(bal);
             const int pos = row >= 0 ? __popcll(bal & ltm) : cnt + __popcll(~bal & ltm);
-            if (row >= 0 || pos < ((cnt + 15) & ~15)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 7) | (uint32_t)lane : PX_PAD;
+            if ((row >= 0 || pos < ((cnt + 15) & ~15)) && !(SPS_ABLATE_FE & 64)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 7) | (uint32_t)lane : PX_PAD;
             cb += (cnt + 15) >> 4;
             // chunk -> offset table: chunk q belongs to offset #{j' : chunks up to and including j' <= q}, counted per lane for
             // q = lane and q = lane + 64 and stored once at the end
@@ -233,7 +234,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       if (lane + 64 < cb) kb[lane + 64] = (unsigned char)(27 * slice + khi);
     }
     if (want_tm && (lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = m;
-    if (eb && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = cb;
+    if (eb && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = (SPS_ABLATE_FE & 64) ? 0 : cb;  // (ablation bit 6: nothing was stored: no chunks to read)
   }
 }
 

@@ -52,6 +52,11 @@
 #undef SPS_ABLATE_STAGE
 #undef SPS_ABLATE_C0FETCH
 #undef SPS_WAVE_TRACE
+#undef SPS_ABLATE_FE  // front-end ablations (tools/fe_ablation.sh): bit 0 hash inserts of k_points_to_blocks, 1 ranking look-back, 2 ancestor
+                      // inserts, 3 adjacency probes, 4 adjacency stores, 5 k_maps block fetches, 6 k_maps stores, 7 k_maps offset loop
+#endif
+#ifndef SPS_ABLATE_FE
+#define SPS_ABLATE_FE 0
 #endif
 
 namespace {
