@@ -124,7 +124,6 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   // tile masks say which entries of the neighbour table were written: a level that keeps only the rulebook (inference-only
   // context, pair-exact layers) needs neither (round 5: five vector instructions per offset less for 87 % of the rows)
   const bool want_tm = nbr != nullptr || rbe == nullptr;
-  const unsigned long long ltm = (1ull << lane) - 1ull;
   const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];
   // Raw buffer loads (offset 0xFFFFFFFF = no access, zeros) for the per-lane optional fetches below: they are branch-free,
   // so the 8 adjacency entries are requested together and the 8 (mask, base) records together -- two round trips.  (Round
@@ -218,7 +217,9 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
             // ONE store per offset: lanes with a pair write their entry at its compacted slot, the first (-cnt & 15) lanes
             // without one write the padding behind the entries (there are always enough: cnt > 48 => 64 - cnt = the padding)
             const int cnt = __popcll(bal);
-            const int pos = row >= 0 ? __popcll(bal & ltm) : cnt + __popcll(~bal & ltm);
+            // lanes below this one WITH a pair: two v_mbcnt (no lane mask, no branch); those WITHOUT one are the rest of them
+            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            const int pos = row >= 0 ? below : cnt + lane - below;
             if ((row >= 0 || pos < ((cnt + 15) & ~15)) && !(SPS_ABLATE_FE & 64)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 7) | (uint32_t)lane : PX_PAD;
             cb += (cnt + 15) >> 4;
             // chunk -> offset table: chunk q belongs to offset #{j' : chunks up to and including j' <= q}, counted per lane for
