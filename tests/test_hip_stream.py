@@ -247,6 +247,26 @@ def test_predict_cli_pipelined_matches_bench_loop():
     assert outs[0] == outs[1]
 
 
+def test_engine_leaves_the_callers_context_alone(net, params):
+    """One of the engine's pipelines runs on the caller's current stream (the hardware queues are loaded evenly that way,
+    DESIGN 3.2) -- on a context of ITS OWN: the shared per-stream context of that stream, which direct calls of the model use,
+    stays dense and keeps its neighbour tables; and the engine's results do not depend on which pipeline took a scan."""
+    from sps_amd.engine import ScanEngine
+    from sps_amd.models.models import get_context
+    scans = [synthetic.small_scene(seed=70 + i, n_scan=1500) for i in range(6)]
+    eng = ScanEngine(net, 0, streams=4, max_rows=max(len(b) for b in scans), table_rows=len(scans))
+    assert eng.streams[0] is eng.main and eng.ctxs[0] is not get_context(0)
+    sums = eng.run_sequence([torch.from_numpy(b) for b in scans])
+    dev = torch.from_numpy(scans[0]).cuda()
+    s, direct = net.forward_metrics(dev, 1)                              # the caller's stream, the shared context
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(direct.cpu().numpy()[0], sums[0])       # (scan 0 ran on the engine's private context)
+    c = get_context(0)
+    assert c.kernel_map(0, 0).shape[0] == 81                             # still a full context: neighbour table at level 0
+    eng2 = ScanEngine(net, 0, streams=2, max_rows=max(len(b) for b in scans), table_rows=len(scans))
+    np.testing.assert_array_equal(eng2.run_sequence([torch.from_numpy(b) for b in scans]), sums)
+
+
 @pytest.mark.timeout(900)
 def test_predict_cli_two_ranks_on_one_gpu_gloo():
     """BASELINE config 5's entry point with W > 1: scripts/predict.py under torch.distributed.run with two ranks sharing
