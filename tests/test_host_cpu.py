@@ -329,3 +329,58 @@ def test_inference_kernels_have_no_serialised_optional_loads():
             assert n <= 4, (name, n, out)     # the supertile's order / count entry (+ nothing in the epilogues)
         elif name in ceilings:
             assert n <= ceilings[name], (name, n, out)
+
+
+def test_bench_cpu_quota_and_engine_pipeline_defaults():
+    """bench.cpu_quota(): what this job may use (affinity / cgroup quota), never more than the host's cores; the engine's
+    pipeline counts are multiples of the runtime's 4 hardware queues."""
+    import bench
+    from sps_amd import engine
+    q = bench.cpu_quota()
+    assert 1 <= q <= (os.cpu_count() or 1)
+    assert engine.DEFAULT_STREAMS % 4 == 0 and engine.SHORT_RUN_STREAMS % 4 == 0 and engine.SHORT_RUN_STREAMS <= engine.DEFAULT_STREAMS
+
+
+def test_kernel_durations_tool_averages_launch_positions(tmp_path):
+    """tools/kernel_durations.py: the launches between two k_points_to_blocks of a rocprofv3 kernel trace are one scan; per launch
+    position the mean duration over the steady-state scans; tagged with the hash of the kernel sources bench.py checks."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = tmp_path / "prof" / "host"
+    d.mkdir(parents=True)
+    names = ["(anonymous namespace)::k_points_to_blocks(float const*)", "void (anonymous namespace)::k_conv<2, 2>((anonymous namespace)::ConvArgs)",
+             "(anonymous namespace)::k_tail(float const*)"]
+    with open(d / "1_kernel_trace.csv", "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp"])
+        t = 0
+        for scan in range(8):
+            for j, nm in enumerate(names):
+                dur = 1000 * (j + 1) + (100 if scan % 2 else 0)
+                w.writerow([nm, t, t + dur])
+                t += dur + 500
+        w.writerow([names[0], t, t + 1000])                      # the start of a ninth scan closes the eighth
+        w.writerow(["at::native::some_torch_kernel", t + 5, t + 6])       # foreign kernels are ignored
+    out = tmp_path / "kd.json"
+    subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_durations.py"), str(tmp_path / "prof"), str(out)], check=True,
+                   capture_output=True)
+    kd = json.load(open(out))
+    import bench
+    assert kd["csrc_sha"] == bench.csrc_sha()
+    assert [n for n, _ in kd["launches"]] == ["k_points_to_blocks", "k_conv<2, 2>", "k_tail"]
+    assert [u for _, u in kd["launches"]] == pytest.approx([1.05, 2.05, 3.05])           # us: mean of the alternating durations
+    assert kd["sum_us"] == pytest.approx(6.15)
+
+
+def test_predict_cli_help_lists_the_reference_options_and_backend():
+    """The CLI keeps the reference's options (-w / -seq / -c, predict.py:15-39) and names the distributed backend switch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "scripts", "predict.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    for opt in ("--weights", "-w", "--sequence", "-seq", "--config", "-c", "--backend", "--batch-size"):
+        assert opt in r.stdout, opt
