@@ -1099,6 +1099,10 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
         const int tz = tz0 + iz;
         const bool hiw = (tz & 2) != 0;  // bit 5 of the position: which half of the 64-bit mask
         const uint32_t w0 = hiw ? m0hi : m0lo, w1 = hiw ? m1hi : m1lo;
+        // the four runs of this z plane that fall into the group's y block are CONSECUTIVE 5-bit fields of the presence map
+        // (c = (dy + 2) + 5 (dz + 2) advances with ty): they are collected with compile-time shifts and placed ONCE per plane
+        // (round 5; rounds 3-4 placed every run with a 64-bit shift and eight selects)
+        uint32_t plane = 0u;
 #pragma unroll
         for (int iy = 0; iy < 4; ++iy) {
           const int ty = ty0 + iy;
@@ -1106,14 +1110,15 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
           const int sh = ((tz & 1) << 4) | ((ty & 3) << 2);
           const uint32_t n0 = (w0 >> sh) & 0xFu, n1 = (w1 >> sh) & 0xFu;
           const uint32_t pres = on ? (((n0 | (n1 << 4)) >> xs) & 0x1Fu) : 0u;
-          const int k0 = 5 * ((ty - py + 2) + 5 * (tz - pz + 2));  // k = 5 c + (dx + 2), c = (dy + 2) + 5 (dz + 2)
-          const unsigned long long wide = (unsigned long long)pres << (k0 & 31);
-          const int wi = on ? (k0 >> 5) & 3 : 0;
-          bm[0] |= wi == 0 ? (uint32_t)wide : 0u;
-          bm[1] |= wi == 1 ? (uint32_t)wide : (wi == 0 ? (uint32_t)(wide >> 32) : 0u);
-          bm[2] |= wi == 2 ? (uint32_t)wide : (wi == 1 ? (uint32_t)(wide >> 32) : 0u);
-          bm[3] |= wi == 3 ? (uint32_t)wide : (wi == 2 ? (uint32_t)(wide >> 32) : 0u);
+          plane |= pres << (5 * iy);
         }
+        const int k0 = 5 * ((ty0 - py + 2) + 5 * (tz - pz + 2));  // k = 5 c + (dx + 2), c = (dy + 2) + 5 (dz + 2); first run of the plane
+        const unsigned long long wide = (unsigned long long)plane << (k0 & 31);
+        const int wi = (k0 >> 5) & 3;  // (a plane past tz1 is empty: wherever it lands)
+        bm[0] |= wi == 0 ? (uint32_t)wide : 0u;
+        bm[1] |= wi == 1 ? (uint32_t)wide : (wi == 0 ? (uint32_t)(wide >> 32) : 0u);
+        bm[2] |= wi == 2 ? (uint32_t)wide : (wi == 1 ? (uint32_t)(wide >> 32) : 0u);
+        bm[3] |= wi == 3 ? (uint32_t)wide : (wi == 2 ? (uint32_t)(wide >> 32) : 0u);
       }
     }
 #pragma unroll
@@ -1122,10 +1127,17 @@ __global__ __launch_bounds__(256) void k_conv0_fused(const int *__restrict__ n_o
       bm[w] |= __shfl_xor(bm[w], 32, 64);
     }
     floatx4 acc = floatx4{0.f, 0.f, 0.f, 0.f};
+    // bit k = 4 g + q of the map: the words shifted by q once, then a sign-extended one-bit field at a compile-time position
+    // ANDed with the bits of the constant input -- two vector instructions per MFMA operand (round 5; a variable shift, a
+    // test and a select before)
+    uint32_t bq[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bq[w] = bm[w] >> q;
+    const uint32_t cbits = __float_as_uint(in_const);
 #pragma unroll
     for (int g = 0; g < 32; ++g) {
-      const int k = 4 * g + q;  // (4g + q) >> 5 == g >> 3
-      const float av = ((bm[g >> 3] >> (k & 31)) & 1u) ? in_const : 0.f;
+      const int k = 4 * g + q;  // (4g + q) >> 5 == g >> 3, and (4g & 31) + q < 32: the same word
+      const float av = __uint_as_float((uint32_t)__builtin_amdgcn_sbfe((int)bq[g >> 3], (4 * g) & 31, 1) & cbits);
       const float bv = r < 8 ? w_s[k * 8 + r] : 0.f;
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
     }
