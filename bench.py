@@ -34,16 +34,19 @@ Prints ONE JSON line on rank 0, including
 """
 from __future__ import annotations
 
-import argparse
-import hashlib
-import json
-import math
-import os
-import sys
 import time
 
-import numpy as np
-import torch
+T_IMPORT0 = time.perf_counter()               # (before numpy / torch: `wall_s.imports_before_main` of the line)
+
+import argparse  # noqa: E402
+import hashlib  # noqa: E402
+import json  # noqa: E402
+import math  # noqa: E402
+import os  # noqa: E402
+import sys  # noqa: E402
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -188,6 +191,8 @@ def main():
                          "much the voxel-row order, which follows the first occurrence of each block, costs in cache locality)")
     args = ap.parse_args()
 
+    t_main = time.perf_counter()
+    wall = {}                                   # where the run's wall time goes (seconds; the driver's clock holds the imports too)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -260,6 +265,7 @@ def main():
         torch.cuda.synchronize()
 
     issue_s = [0.0]
+    wall["setup_workload_weights_engine"] = round(time.perf_counter() - t_main, 2)
 
     def timed_region(feed):
         """W untimed + exactly K timed steps; returns (wall seconds incl. the metric all-gather, GPU ms first start ->
@@ -321,6 +327,8 @@ def main():
             dist.destroy_process_group()
         return
 
+    wall["timed_regions_with_warmup"] = round(time.perf_counter() - t_main - wall["setup_workload_weights_engine"], 2)
+    t_phase = time.perf_counter()
     # ---- whole-job numbers ------------------------------------------------------------------
     total_scans = K * nb * world
     value = total_scans / elapsed
@@ -444,6 +452,8 @@ def main():
                                      for k, v in sorted(classes.items(), key=lambda kv: -kv[1]["us"])),
         )
 
+    wall["stage_pass_and_roofline"] = round(time.perf_counter() - t_phase, 2)
+    t_phase = time.perf_counter()
     # ---- CPU baseline + parity: the oracle's C restatement on this box's host cores (checker only) ----
     cpu = None
     parity = None
@@ -505,6 +515,9 @@ def main():
                   "dIoU_gpu": dio_gpu, "dIoU_oracle": dio_ref,
                   "confusion_TP_FP_FN_TN_gpu": conf_gpu, "confusion_TP_FP_FN_TN_oracle": conf_ref}
 
+    wall["cpu_baseline_and_parity"] = round(time.perf_counter() - t_phase, 2)
+    wall["main_total"] = round(time.perf_counter() - t_main, 2)
+    wall["imports_before_main"] = round(t_main - T_IMPORT0, 2)
     out = {
         "metric": "scans/sec @100k pts, 0.1 m voxel", "value": round(value, 2), "unit": "scans/s",
         "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -521,7 +534,7 @@ def main():
         "resident_value": resident["value"],
         "dist_backend": (dist.get_backend() if dist is not None else None), "dist_world_size": (dist.get_world_size() if dist is not None else 1),
         "host_cores": os.cpu_count(), "host_placement": placement,
-        "host_issue_ms_per_step": round(host_issue_ms, 4),
+        "host_issue_ms_per_step": round(host_issue_ms, 4), "wall_s": wall,
     }
     print(json.dumps(out))
     if dist is not None:
