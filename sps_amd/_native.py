@@ -38,6 +38,11 @@ def _load() -> C.CDLL:
             path = _build.build()
         elif not os.path.exists(path):
             raise ImportError("libsps_hip.so is missing and hipcc is not available to build it")
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 / libhsa-runtime64.  Loaded AFTER torch, this library binds
+    # to the copies torch already mapped (same SONAME); loaded BEFORE it, /opt/rocm's copies come in first and the process ends
+    # up with two runtimes, of which the second finds "no ROCm-capable device" (seen with __graft_entry__.build() followed by
+    # smoke() in one process).  The host side of this package is PyTorch's anyway (device memory, streams).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
     sig = {

@@ -407,3 +407,14 @@ def test_rccl_path_runs_at_world_size_one():
                      os.path.join("config", "config.yaml"), "--force-dist", "--streams", "3"])
     assert r.returncode == 0, r.stderr[-3000:]
     assert "dIoU" in r.stdout and "Loss" in r.stdout
+
+
+@pytest.mark.timeout(600)
+def test_binding_imported_before_torch_shares_torchs_hip_runtime():
+    """__graft_entry__.build() imports the binding before anything imports torch; smoke() in the same process must still
+    find the GPU (one HIP runtime per process: the binding pulls torch in before it maps libsps_hip.so)."""
+    code = ("import sys; from sps_amd import _native; assert 'torch' in sys.modules; "
+            "cx = _native.Context(0); import torch; assert torch.cuda.is_available(); "
+            "x = torch.zeros(8, device='cuda'); torch.cuda.synchronize(); print('one runtime', cx.arena_bytes() >= 0)")
+    r = _run([sys.executable, "-c", code])
+    assert r.returncode == 0 and "one runtime True" in r.stdout, r.stderr[-2000:]
