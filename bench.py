@@ -337,11 +337,16 @@ def main():
     confusion = {k: float(np.mean([m[k] for m in per_scan])) for k in ("tp", "fp", "fn", "tn")}
 
     # ---- roofline: algorithmic bytes of THIS run / GPU time per step --------------------------
-    # (the engine's LAST pipeline: a side stream whose shared per-stream context the engine uses -- the pipeline on the
-    #  current stream runs on a private context -- so that net(...) on that stream and the introspection meet the same one)
+    # (one of the engine's own pipelines: the same compact, inference-only context and the same native call -- forward + metric
+    #  sums -- as the timed steps)
     ctx = eng.ctxs[-1]
-    with torch.cuda.stream(streams[-1]):
-        net(batches[0])
+    probe_out = torch.empty((nb, 8), dtype=torch.float64, device=dev)
+
+    def probe():
+        with torch.cuda.stream(streams[-1]):
+            net.forward_metrics(batches[0], nb, probe_out, ctx=ctx)
+
+    probe()
     torch.cuda.synchronize()
     V = ctx.level_counts()
     pairs3 = [sum(ctx.map_pairs(l)) for l in range(5)]
@@ -355,8 +360,7 @@ def main():
         ctx.profile_enable(True)
         acc, reps, order = {}, 10, []
         for _ in range(reps):
-            with torch.cuda.stream(streams[-1]):
-                net(batches[0])
+            probe()
             for name, ms in ctx.profile_read():
                 if name not in acc:
                     order.append(name)

@@ -51,7 +51,7 @@ class ScanEngine:
             # the current stream's pipeline gets a context of ITS OWN: the shared per-stream context of that stream
             # (get_context) belongs to whoever calls the model directly there and must not become compact / inference-only
             from ._native import Context
-            self.ctxs = [Context(self.index) if (st is self.main and S > 1) else get_context(self.index, st.cuda_stream)
+            self.ctxs = [Context(self.index) if st is self.main else get_context(self.index, st.cuda_stream)
                          for st in self.streams]
         # LiDAR-sized arenas (2.2 KB instead of 6.9 KB of device memory per point and context): a cloud whose coarse
         # levels do not thin out like a LiDAR scan's aborts its forward on the device; finish() then raises SpsError

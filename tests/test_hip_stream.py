@@ -265,6 +265,10 @@ def test_engine_leaves_the_callers_context_alone(net, params):
     assert c.kernel_map(0, 0).shape[0] == 81                             # still a full context: neighbour table at level 0
     eng2 = ScanEngine(net, 0, streams=2, max_rows=max(len(b) for b in scans), table_rows=len(scans))
     np.testing.assert_array_equal(eng2.run_sequence([torch.from_numpy(b) for b in scans]), sums)
+    eng1 = ScanEngine(net, 0, streams=1, max_rows=max(len(b) for b in scans), table_rows=len(scans))   # strictly serial: the same
+    assert eng1.streams == [eng1.main] and eng1.ctxs[0] is not get_context(0)
+    np.testing.assert_array_equal(eng1.run_sequence([torch.from_numpy(b) for b in scans]), sums)
+    assert get_context(0).kernel_map(0, 0).shape[0] == 81
 
 
 @pytest.mark.timeout(900)
