@@ -2,7 +2,8 @@
 """bench.py -- scans/sec of the SPS per-scan hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W [--config 2|3|4]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...; without a launcher in
+   the environment `python bench.py --gpus N` starts that command itself as a child process and relays rank 0's line)
 
 A "step" is one pass of the whole hot path over one batch of synthetic input that is already resident in HBM:
 quantise + voxel hash + stride pyramid + kernel maps + the 33 sparse convs of CustomMinkUNet14 (fp32) + slice +
@@ -196,10 +197,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  A CHILD process (this one has not
+        # touched the GPU: nothing above calls into HIP), never an exec; rank 0's JSON line and the exit code are relayed.
+        from sps_amd import parallel
+        raise SystemExit(parallel.spawn_ranks(args.gpus, os.path.abspath(__file__), sys.argv[1:]))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 "
-                             f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 --master-port P bench.py --gpus {args.gpus}")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
     if args.backend != "nccl":
         local = local % max(torch.cuda.device_count(), 1)      # debug: several ranks may share one GPU

@@ -75,9 +75,16 @@ def batched(loader, k):
               help="torch.distributed backend (default: $SPS_DIST_BACKEND, else nccl = RCCL over xGMI).  gloo lets several ranks "
                    "share ONE GPU (rank -> device LOCAL_RANK mod device count): how the sharding and the padded metric "
                    "all-gather are tested on a one-GPU box")
+@click.option("--gpus", type=int, default=None,
+              help="data-parallel ranks, one per GPU (BASELINE config 5).  Without a launcher in the environment the ranks are "
+                   "started here (python -m torch.distributed.run --nproc-per-node N, a child process); under torchrun it "
+                   "must equal WORLD_SIZE")
 @click.option("--host-items", is_flag=True, help="assemble the items on the host (DataLoader workers + scipy cKDTree, as the "
                                                  "reference does) instead of on the device")
-def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams, timing, force_dist, backend, host_items):
+def main(weights, sequence, config, n_synth, batch_size, me_conventions, streams, timing, force_dist, backend, gpus, host_items):
+    if gpus and gpus > 1 and "WORLD_SIZE" not in os.environ:        # nothing has touched the GPU yet: start the ranks
+        raise SystemExit(parallel.spawn_ranks(gpus, os.path.abspath(__file__), sys.argv[1:]))
+    assert not gpus or gpus == int(os.environ.get("WORLD_SIZE", "1")), "--gpus does not match WORLD_SIZE"
     cfg = yaml.safe_load(open(config))
     if me_conventions:
         cfg["MODEL"]["ME_CONVENTIONS"] = me_conventions

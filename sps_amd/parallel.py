@@ -20,6 +20,26 @@ def shard_indices(n_scans: int, rank: int, world: int):
     return list(range(rank, n_scans, world))
 
 
+def spawn_ranks(n: int, script: str, argv) -> int:
+    """Run ``script argv`` as n ranks of one node under ``torch.distributed.run`` -- the driver's N > 1 command line -- in a
+    CHILD process and return its exit code.  For entry points called as ``python bench.py --gpus N`` without a launcher:
+    the caller must not have touched the GPU yet (a child, never an exec of a process that holds HIP state).  The
+    rendezvous is 127.0.0.1 on a free port (the container's hostname may not resolve)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={int(n)}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
 def gather_metric_rows(local_rows: torch.Tensor, world: int, group=None, force: bool = False) -> torch.Tensor:
     """All-gather the ranks' [n_local, ROW] rows (n_local may differ by one) -> [n_total, ROW] sorted by
     scan index.  One padded all_gather; the pad rows carry scan_idx = -1 and are dropped.  ``force`` runs the

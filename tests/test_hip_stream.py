@@ -294,6 +294,48 @@ def test_predict_cli_two_ranks_on_one_gpu_gloo():
         assert "timing: 7 scans" in two.stdout and "(2 GPU(s)" in two.stdout, two.stdout
 
 
+@pytest.mark.timeout(1200)
+def test_bench_and_predict_start_their_own_ranks():
+    """`python bench.py --gpus N` / `scripts/predict.py --gpus N` WITHOUT torchrun (no WORLD_SIZE in the environment): the
+    entry point starts `python -m torch.distributed.run --nproc-per-node N` itself as a child process -- before anything of
+    its own touched the GPU -- and relays rank 0's output and the exit code.  Two ranks, then FIVE sharing this box's one GPU
+    (with the test process itself that is the six processes the box's guard admits on the card; the 8-rank shard + padded
+    gather runs on CPU in tests/test_parallel_gloo.py): 13 scans on 5 ranks = 3,3,3,2,2 rows per rank, the one-rank run's
+    six lines."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+
+    def run(cmd):
+        return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+
+    for n in (2, 5):
+        r = run([sys.executable, "bench.py", "--gpus", str(n), "--backend", "gloo", "--steps", "7", "--warmup", "2", "--azimuth", "60",
+                 "--streams", "2", "--no-cpu-baseline", "--no-stages"])
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == n and d["dist_world_size"] == n and d["steps"] == 7 and d["config"]["sharding"] == f"dp{n}"
+        assert d["value"] == pytest.approx(n * 7 / (d["ms_per_step"] * 7e-3), rel=1e-3)
+    r = run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--steps", "0x"])        # a failing child fails the caller
+    assert r.returncode != 0
+
+    base = [sys.executable, os.path.join("scripts", "predict.py"), "--synthetic", "13", "-c", os.path.join("config", "config.yaml"),
+            "--streams", "2"]
+
+    def six(stdout):
+        lines = {l.split(" ")[0]: l for l in stdout.splitlines()}
+        return [lines[k] for k in ("Loss", "R2", "dIoU", "Precision", "Recall", "F1")]
+
+    one = run(base)
+    assert one.returncode == 0, one.stderr[-3000:]
+    many = run(base + ["--gpus", "5", "--backend", "gloo", "--timing"])
+    assert many.returncode == 0, many.stderr[-3000:]
+    assert many.stdout.count("########## Inference Metrics ##########") == 1
+    assert six(many.stdout) == six(one.stdout), (many.stdout, one.stdout)
+    assert "timing: 13 scans" in many.stdout and "(5 GPU(s)" in many.stdout, many.stdout
+
+
 def test_compact_arena_overflow_aborts_reports_and_recovers(net, params):
     """sps_ctx_set_level_fractions: LiDAR-sized level arrays.  A LiDAR-like cloud runs unchanged in a third of the memory;
     a cloud whose coarse levels do not thin out (every point its own voxel at every stride) makes its forward abort on the
