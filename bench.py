@@ -430,7 +430,9 @@ def main():
         kj = json.load(open(kp))
         seq = [s for s in stages if s["kernel"] != "(memset)"]
         n_launch = sum(len(s["kernel"].split("+")) for s in seq)
-        if kj.get("csrc_sha") == csrc_sha() and len(kj["launches"]) == n_launch:
+        same_run = (kj.get("workload", {"azimuth": args.azimuth, "scenes": args.scenes}) == {"azimuth": args.azimuth, "scenes": args.scenes}
+                    and kj.get("device", torch.cuda.get_device_name(dev)) == torch.cuda.get_device_name(dev))
+        if kj.get("csrc_sha") == csrc_sha() and len(kj["launches"]) == n_launch and same_run:
             i = 0
             for s in seq:
                 k = len(s["kernel"].split("+"))
@@ -477,7 +479,7 @@ def main():
         # threads); the serial voxel hash (first-occurrence order) bounds it: take the best of a few thread counts (one pass
         # each) and report the count actually used as `cores`
         best, single = None, None
-        sweep = sorted({t for t in (1, 4, 8, 16, 32, 64) if t < quota} | {quota})
+        sweep = sorted({t for t in (1, 4, 8, 16, 32, 64, 128, 256) if t < quota} | {quota})
         for th in sweep:
             if args.config != 2 and th == 1:
                 continue

@@ -42,7 +42,9 @@ def _load() -> C.CDLL:
     # to the copies torch already mapped (same SONAME); loaded BEFORE it, /opt/rocm's copies come in first and the process ends
     # up with two runtimes, of which the second finds "no ROCm-capable device" (seen with __graft_entry__.build() followed by
     # smoke() in one process).  The host side of this package is PyTorch's anyway (device memory, streams).
-    import torch  # noqa: F401
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:     # (the ctypes binding alone works without torch)
+        import torch  # noqa: F401
     lib = C.CDLL(path)
     vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
     sig = {

@@ -146,7 +146,7 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
     const int nt = ok ? (int)((L.bkey[r] >> 54) & 0x1F) + slice - 1 : -1;
     const bool act = nt >= 0 && nt < 32 && ((tocc >> nt) & 1u);
     if (!__any(act)) {
-      if ((lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = 0u;
+      if (want_tm && (lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = 0u;
       if (rbc && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = 0;
       continue;
     }
@@ -466,6 +466,7 @@ __device__ inline void tile_order_body(const TileOrderArgs &a, int which) {
   const int l = TILE_ORDER_FIRST_LEVEL + which;
   const int nt = (a.counts[l] + 15) >> 4;
   const uint32_t *__restrict__ tm = a.tm3[l];
+  if (!tm) return;  // a level that keeps only a rulebook has no tile masks (and no k_conv launch that would read the order)
   if (threadIdx.x < 88) hist[threadIdx.x] = 0, cursor[threadIdx.x] = 0;
   __syncthreads();
   for (int t = threadIdx.x; t < nt; t += blockDim.x) {

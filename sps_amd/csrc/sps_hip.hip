@@ -776,8 +776,9 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
     int gto = 0;
     if (TILE_ORDER != 0) {
       for (int l = 0; l < NLV; ++l) {
-        to.tm3[l] = c->lv[l].tm3, to.order[l] = c->lv[l].tile_order;
         const bool px = l < PX_LEVELS && ((px_levels() >> l) & 1) && c->lv[l].px_order;
+        // k_maps writes tile masks where a neighbour table is kept or no rulebook replaces it (`want_tm`, build_nbr3)
+        to.tm3[l] = (c->lv[l].nbr3 || !px) ? c->lv[l].tm3 : nullptr, to.order[l] = c->lv[l].tile_order;
         to.rb_cnt[l] = px ? c->lv[l].rb_cnt : nullptr, to.px_sorted[l] = c->lv[l].px_sorted, to.px_order[l] = c->lv[l].px_order;
       }
       to.counts = c->counts;
@@ -1996,9 +1997,9 @@ int sps_get_tile_masks(sps_ctx *c, int which, uint32_t *masks_dev, int64_t *n_ti
   int rc = sps_level_counts(c, cnt);
   if (rc != SPS_OK) return rc;
   const int level = which == 5 ? 0 : which;
-  *n_tiles = (cnt[level] + 15) / 16;
   if (which <= 4 && !c->lv[which].nbr3)
     return fail(SPS_ERR_INVALID, "an inference-only context keeps neither neighbour table nor tile masks at level %d", which);
+  *n_tiles = (cnt[level] + 15) / 16;
   const uint32_t *src = which == 5 ? c->tm5 : c->lv[which].tm3;
   if (masks_dev && *n_tiles > 0)
     HIP_TRY(hipMemcpy(masks_dev, src, (size_t)*n_tiles * 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice));

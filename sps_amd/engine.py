@@ -98,6 +98,8 @@ class ScanEngine:
                     cx.reserve(int(max_rows))
                 if cx.weights is not w:
                     cx.set_weights(w)
+                if st is not self.main:
+                    st.wait_stream(self.main)          # `warm` / `out` are filled on the main stream
                 with torch.cuda.stream(st):
                     self.net.forward_metrics(warm, 1, out, ctx=cx)
             if table_rows:

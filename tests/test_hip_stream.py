@@ -247,6 +247,14 @@ def test_predict_cli_pipelined_matches_bench_loop():
     assert outs[0] == outs[1]
 
 
+def _same_sums(a, b):
+    """Metric sums of two runs of the same scan: the five counts exactly; the three f64 sums (squared error, labels, labels
+    squared) meet through f64 atomics of several workgroups -- their last bit follows the arrival order (tools/soak_engine.py)."""
+    a, b = np.asarray(a), np.asarray(b)
+    np.testing.assert_array_equal(a[..., :5], b[..., :5])
+    np.testing.assert_allclose(a[..., 5:], b[..., 5:], rtol=1e-12, atol=0)
+
+
 def test_engine_leaves_the_callers_context_alone(net, params):
     """One of the engine's pipelines runs on the caller's current stream (the hardware queues are loaded evenly that way,
     DESIGN 3.2) -- on a context of ITS OWN: the shared per-stream context of that stream, which direct calls of the model use,
@@ -260,14 +268,14 @@ def test_engine_leaves_the_callers_context_alone(net, params):
     dev = torch.from_numpy(scans[0]).cuda()
     s, direct = net.forward_metrics(dev, 1)                              # the caller's stream, the shared context
     torch.cuda.synchronize()
-    np.testing.assert_array_equal(direct.cpu().numpy()[0], sums[0])       # (scan 0 ran on the engine's private context)
+    _same_sums(direct.cpu().numpy()[0], sums[0])                          # (scan 0 ran on the engine's private context)
     c = get_context(0)
     assert c.kernel_map(0, 0).shape[0] == 81                             # still a full context: neighbour table at level 0
     eng2 = ScanEngine(net, 0, streams=2, max_rows=max(len(b) for b in scans), table_rows=len(scans))
-    np.testing.assert_array_equal(eng2.run_sequence([torch.from_numpy(b) for b in scans]), sums)
+    _same_sums(eng2.run_sequence([torch.from_numpy(b) for b in scans]), sums)
     eng1 = ScanEngine(net, 0, streams=1, max_rows=max(len(b) for b in scans), table_rows=len(scans))   # strictly serial: the same
     assert eng1.streams == [eng1.main] and eng1.ctxs[0] is not get_context(0)
-    np.testing.assert_array_equal(eng1.run_sequence([torch.from_numpy(b) for b in scans]), sums)
+    _same_sums(eng1.run_sequence([torch.from_numpy(b) for b in scans]), sums)
     assert get_context(0).kernel_map(0, 0).shape[0] == 81
 
 

@@ -28,7 +28,15 @@ def main():
     scans = [s for s in scans if len(s) == n]
     names = [r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0] for r in scans[0]]
     us = [sum((int(s[i]["End_Timestamp"]) - int(s[i]["Start_Timestamp"])) for s in scans) / len(scans) / 1000.0 for i in range(n)]
-    out = {"csrc_sha": csrc_sha(), "scans_averaged": len(scans), "launches": [[nm, round(u, 3)] for nm, u in zip(names, us)],
+    # the workload and device of the traced run (bench.py attaches the durations only to a line of the same workload): the
+    # collect script runs `bench.py --streams 1` with its default --azimuth / --scenes
+    workload = {"azimuth": int(os.environ.get("SPS_KD_AZIMUTH", "1750")), "scenes": int(os.environ.get("SPS_KD_SCENES", "4"))}
+    device = None
+    agents = glob.glob(sys.argv[1] + "/*/*agent_info.csv")
+    if agents:
+        gpus = [r for r in csv.DictReader(open(agents[0])) if r.get("Agent_Type") == "GPU"]
+        device = (gpus[0].get("Product_Name") or gpus[0].get("Name")) if gpus else None
+    out = {"csrc_sha": csrc_sha(), "workload": workload, **({"device": device} if device else {}), "scans_averaged": len(scans), "launches": [[nm, round(u, 3)] for nm, u in zip(names, us)],
            "sum_us": round(sum(us), 2),
            "method": "rocprofv3 --kernel-trace over bench.py --streams 1; per launch position the mean duration over the "
                      "steady-state scans of the trace"}

@@ -1,5 +1,5 @@
 #!/bin/bash
-# What does each kernel class cost the PIPELINED rate?  Diagnostic build (tools/ab_build.sh diag -DSPS_DIAG -DSPS_WS_FIRST_LEVEL=9
+# What does each kernel class cost the PIPELINED rate?  Diagnostic build (tools/ab_build.sh diag -DSPS_DIAG
 # -DSPS_FUSE_UP=0), bench.py with one class of convolution launches skipped at a time (wrong results, of course).
 # usage (GPU box): bash tools/skip_class_sweep.sh
 mkdir -p gpurun_out

@@ -13,7 +13,7 @@ import tempfile
 lib = os.path.join(tempfile.mkdtemp(prefix="sps_trace_"), "libsps_hip_trace.so")
 os.environ["SPS_LIB"] = lib
 try:
-    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSPS_DIAG", "-DSPS_WS_FIRST_LEVEL=9", "-DSPS_WAVE_TRACE",
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DSPS_DIAG", "-DSPS_WAVE_TRACE",
                            *args.flags.split(), "-o", lib, os.path.join(ROOT, "sps_amd/csrc/sps_hip.hip")],
                           stderr=subprocess.DEVNULL)
     os.environ["SPS_TRACE_LAYER"] = args.layer
