@@ -128,6 +128,15 @@ def cpu_quota():
     return max(1, n)
 
 
+def same_device(a, b):
+    """Product names as rocprofv3's agent table and torch spell them ("AMD Instinct MI355X" either way, give or take a
+    prefix); an absent name does not veto."""
+    if not a or not b:
+        return True
+    a, b = a.lower().strip(), b.lower().strip()
+    return a in b or b in a
+
+
 def csrc_sha():
     h = hashlib.sha256()
     d = os.path.join(ROOT, "sps_amd", "csrc")
@@ -431,7 +440,7 @@ def main():
         seq = [s for s in stages if s["kernel"] != "(memset)"]
         n_launch = sum(len(s["kernel"].split("+")) for s in seq)
         same_run = (kj.get("workload", {"azimuth": args.azimuth, "scenes": args.scenes}) == {"azimuth": args.azimuth, "scenes": args.scenes}
-                    and kj.get("device", torch.cuda.get_device_name(dev)) == torch.cuda.get_device_name(dev))
+                    and same_device(kj.get("device"), torch.cuda.get_device_name(dev)))
         if kj.get("csrc_sha") == csrc_sha() and len(kj["launches"]) == n_launch and same_run:
             i = 0
             for s in seq:

@@ -317,7 +317,7 @@ def test_bench_and_predict_start_their_own_ranks():
         return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
 
     for n in (2, 5):
-        r = run([sys.executable, "bench.py", "--gpus", str(n), "--backend", "gloo", "--steps", "7", "--warmup", "2", "--azimuth", "60",
+        r = run([sys.executable, "bench.py", "--gpus", str(n), "--backend", "gloo", "--steps", "7", "--warmup", "2", "--azimuth", "500",
                  "--streams", "2", "--no-cpu-baseline", "--no-stages"])
         assert r.returncode == 0, r.stderr[-3000:]
         lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
