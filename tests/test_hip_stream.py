@@ -306,17 +306,17 @@ def test_predict_cli_two_ranks_on_one_gpu_gloo():
 def test_bench_and_predict_start_their_own_ranks():
     """`python bench.py --gpus N` / `scripts/predict.py --gpus N` WITHOUT torchrun (no WORLD_SIZE in the environment): the
     entry point starts `python -m torch.distributed.run --nproc-per-node N` itself as a child process -- before anything of
-    its own touched the GPU -- and relays rank 0's output and the exit code.  Two ranks, then FIVE sharing this box's one GPU
-    (with the test process itself that is the six processes the box's guard admits on the card; the 8-rank shard + padded
-    gather runs on CPU in tests/test_parallel_gloo.py): 13 scans on 5 ranks = 3,3,3,2,2 rows per rank, the one-rank run's
-    six lines."""
+    its own touched the GPU -- and relays rank 0's output and the exit code.  Two ranks, then THREE sharing this box's one GPU
+    (the box's guard admits six processes on the card, the test process and the launchers included: five ranks were killed
+    by it; the 8-rank shard + padded gather runs on CPU in tests/test_parallel_gloo.py): 13 scans on 3 ranks = 5,4,4 rows
+    per rank, the one-rank run's six lines."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
 
     def run(cmd):
         return subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
 
-    for n in (2, 5):
+    for n in (2, 3):
         r = run([sys.executable, "bench.py", "--gpus", str(n), "--backend", "gloo", "--steps", "7", "--warmup", "2", "--azimuth", "500",
                  "--streams", "2", "--no-cpu-baseline", "--no-stages"])
         assert r.returncode == 0, r.stderr[-3000:]
@@ -337,11 +337,11 @@ def test_bench_and_predict_start_their_own_ranks():
 
     one = run(base)
     assert one.returncode == 0, one.stderr[-3000:]
-    many = run(base + ["--gpus", "5", "--backend", "gloo", "--timing"])
+    many = run(base + ["--gpus", "3", "--backend", "gloo", "--timing"])
     assert many.returncode == 0, many.stderr[-3000:]
     assert many.stdout.count("########## Inference Metrics ##########") == 1
     assert six(many.stdout) == six(one.stdout), (many.stdout, one.stdout)
-    assert "timing: 13 scans" in many.stdout and "(5 GPU(s)" in many.stdout, many.stdout
+    assert "timing: 13 scans" in many.stdout and "(3 GPU(s)" in many.stdout, many.stdout
 
 
 def test_compact_arena_overflow_aborts_reports_and_recovers(net, params):
