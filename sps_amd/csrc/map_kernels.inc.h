@@ -105,10 +105,15 @@ __device__ inline void lookup_run(const LevelView &L, int u, int dy, int dz, int
 // present-offset mask of a 16-row tile has one 32-bit WORD PER TIME SLICE (word dt+1, bit (dx+1)+3(dy+1)+9(dz+1);
 // offset k = 27 * word + bit), assembled in registers from ballots (every lane of the tile's 16-lane group holds
 // the same word) and written with one plain store: no atomics, and the mask words need no zero fill.
-__device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
-  int local;
-  const int l = level_of_chunk(a, 0, local, bid);
-  const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
+// Round 6 (the 27-offset loop is the launch: instruction issue): TM (tile masks + neighbour table) and RB
+// (rulebook) are compile-time, so an offset no longer pays two wave-uniform tests and their branches; the neighbour lookup
+// works on the 4-bit x run of the (y, z) line inside each of the two candidate blocks -- one bit-field extract for the run and
+// one prefix popcount per block and (dy, dz), shared by the three dx offsets, instead of a 64-bit shift, a 64-bit mask and two
+// popcounts behind an exec-masked branch per offset; an offset no row of the wave has skips the rulebook code; and the
+// chunk -> offset table is written by lanes 0..26 at the end (lane j = offset j: first chunk and chunk count collected with
+// one compare-and-select per offset) instead of two compare-and-add pairs per offset and lane.
+template <bool TM, bool RB>
+__device__ inline void build_nbr3_t(const MapsArgs &a, int l, int local, int nchunks, int slice) {
   const int n = a.counts[l];
   const LevelView L = a.L[l];
   int *__restrict__ nbr = a.nbr3[l];
@@ -121,9 +126,6 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
   uint32_t *__restrict__ rbe = a.rb_e[l];
   unsigned char *__restrict__ rbk = a.rb_k[l];
   int *__restrict__ rbc = a.rb_cnt[l];
-  // tile masks say which entries of the neighbour table were written: a level that keeps only the rulebook (inference-only
-  // context, pair-exact layers) needs neither (round 5: five vector instructions per offset less for 87 % of the rows)
-  const bool want_tm = nbr != nullptr || rbe == nullptr;
   const uint32_t tocc = reinterpret_cast<const uint32_t *>(a.counts)[TOCC];
   // Raw buffer loads (offset 0xFFFFFFFF = no access, zeros) for the per-lane optional fetches below: they are branch-free,
   // so the 8 adjacency entries are requested together and the 8 (mask, base) records together -- two round trips.  (Round
@@ -146,8 +148,8 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
     const int nt = ok ? (int)((L.bkey[r] >> 54) & 0x1F) + slice - 1 : -1;
     const bool act = nt >= 0 && nt < 32 && ((tocc >> nt) & 1u);
     if (!__any(act)) {
-      if (want_tm && (lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = 0u;
-      if (rbc && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = 0;
+      if (TM && (lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = 0u;
+      if (RB && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = 0;
       continue;
     }
     const uint32_t adj4 = ((uint32_t)r * 81u + (uint32_t)slice * 27u) * 4u;
@@ -172,17 +174,28 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       mlo[c] = q.x, mhi[c] = q.y, bs[c] = (int)q.z;
       if constexpr (SPS_ABLATE_FE & 32) mlo[c] = 0x0F0F0F0Fu & (uint32_t)(nbv[c] + 1), mhi[c] = mlo[c];  // (some neighbours, no memory)
     }
+    // the three dx offsets: which of the two x blocks, and the bit inside the 4-bit x run (the same for every (dy, dz))
+    bool oxv[3];
+    uint32_t txl[3], txm[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const int tx = px + d - 1;
+      oxv[d] = (tx >> 2) != 0;
+      txl[d] = (uint32_t)(tx & 3);
+      txm[d] = (1u << txl[d]) - 1u;
+    }
     uint32_t m = 0u;
-    int cb = 0;  // chunks written to the segment so far
-    int klo = 0, khi = 0;
-    uint32_t *__restrict__ eb = rbe ? rbe + ((size_t)(u >> 6) * PX_CH_MAX + (size_t)slice * PX_SEG_CH) * 16 : nullptr;
-    unsigned char *__restrict__ kb = rbk ? rbk + (size_t)(u >> 6) * PX_KSTRIDE + slice * 112 : nullptr;
+    int cb = 0;            // chunks written to the segment so far (wave-uniform)
+    uint32_t kinfo = 0u;   // lane j < 27: first chunk | chunk count << 16 of offset j of this slice
+    uint32_t *__restrict__ eb = RB ? rbe + ((size_t)(u >> 6) * PX_CH_MAX + (size_t)slice * PX_SEG_CH) * 16 : nullptr;
+    unsigned char *__restrict__ kb = RB ? rbk + (size_t)(u >> 6) * PX_KSTRIDE + slice * 112 : nullptr;
     // (all 27 offsets unrolled: 125 VGPRs + spilled SGPRs, 29 us instead of 22.  Measured and dropped as well: 32-bit halves of
     //  the masks + the per-tile bits kept in scalar registers -- fewer VALU instructions, 98 VGPRs, 27 us)
 #pragma unroll 1
     for (int dz = -1; dz <= ((SPS_ABLATE_FE & 128) ? -2 : 1); ++dz) {  // (ablation bit 7: no offset is walked)
       const int tz = pz + dz;
       const bool oz = (tz >> 2) != 0;
+      const bool half = (tz & 2) != 0;  // the (y, z) line lies in the upper mask word
       uint32_t zlo[4], zhi[4];
       int zb[4];
 #pragma unroll
@@ -191,52 +204,71 @@ __device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
       for (int dy = -1; dy <= 1; ++dy) {
         const int ty = py + dy;
         const bool oy = (ty >> 2) != 0;
-        const int nbit0 = ((tz & 3) << 4) | ((ty & 3) << 2);
-        uint32_t ylo[2], yhi[2];
-        int yb[2];
+        const uint32_t sh = (uint32_t)((((tz & 1) << 4) | ((ty & 3) << 2)));  // bit of the line's first voxel inside its word
+        uint32_t nib[2];
+        int pre[2];
 #pragma unroll
-        for (int k = 0; k < 2; ++k) ylo[k] = oy ? zlo[k + 2] : zlo[k], yhi[k] = oy ? zhi[k + 2] : zhi[k], yb[k] = oy ? zb[k + 2] : zb[k];
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t lo = oy ? zlo[k + 2] : zlo[k], hi = oy ? zhi[k + 2] : zhi[k];
+          const int b = oy ? zb[k + 2] : zb[k];
+          const uint32_t word = half ? hi : lo;
+          nib[k] = (word >> sh) & 0xFu;                                            // the 4-bit x run of the line
+          pre[k] = b + (half ? __popc(lo) : 0) + __popc(word & ((1u << sh) - 1u));  // row of the run's first voxel
+        }
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-          const int tx = px + dx;
-          const bool ox = (tx >> 2) != 0;
-          const unsigned long long mk = ((unsigned long long)(ox ? yhi[1] : yhi[0]) << 32) | (ox ? ylo[1] : ylo[0]);
-          const int base = ox ? yb[1] : yb[0];
-          const int nbit = nbit0 | (tx & 3);
-          int row = -1;
-          if ((mk >> nbit) & 1ull) row = base + __popcll(mk & ((1ull << nbit) - 1ull));
-          const int j = (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);  // bit inside the slice word
-          const unsigned long long bal = __ballot(row >= 0);
-          if (want_tm) {  // wave-uniform
+          const uint32_t nibx = oxv[dx + 1] ? nib[1] : nib[0];
+          const int prex = oxv[dx + 1] ? pre[1] : pre[0];
+          const bool present = (nibx >> txl[dx + 1]) & 1u;
+          const int row = present ? prex + __popc(nibx & txm[dx + 1]) : -1;
+          const int jj = (dx + 1) + 3 * (dy + 1);
+          const int j = jj + 9 * (dz + 1);  // bit inside the slice word
+          const unsigned long long bal = __ballot(present);
+          if constexpr (TM) {
             const bool any = ((bal >> (lane & 48)) & 0xFFFFull) != 0ull;  // some row of this lane's 16-row tile has it
             // the convolution only reads (tile, k) entries whose mask bit is set: skip the store otherwise
             if (any && ok && nbr && !(SPS_ABLATE_FE & 64)) nbr[(size_t)(27 * slice + j) * ldn + u] = row;  // (ablation bit 6: no stores)
             m |= any ? 1u << j : 0u;
           }
-          if (eb) {  // wave-uniform
-            // ONE store per offset: lanes with a pair write their entry at its compacted slot, the first (-cnt & 15) lanes
-            // without one write the padding behind the entries (there are always enough: cnt > 48 => 64 - cnt = the padding)
-            const int cnt = __popcll(bal);
-            // lanes below this one WITH a pair: two v_mbcnt (no lane mask, no branch); those WITHOUT one are the rest of them
-            const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-            const int pos = row >= 0 ? below : cnt + lane - below;
-            if ((row >= 0 || pos < ((cnt + 15) & ~15)) && !(SPS_ABLATE_FE & 64)) eb[cb * 16 + pos] = row >= 0 ? ((uint32_t)row << 7) | (uint32_t)lane : PX_PAD;
-            cb += (cnt + 15) >> 4;
-            // chunk -> offset table: chunk q belongs to offset #{j' : chunks up to and including j' <= q}, counted per lane for
-            // q = lane and q = lane + 64 and stored once at the end
-            klo += lane >= cb ? 1 : 0;
-            khi += lane + 64 >= cb ? 1 : 0;
+          if constexpr (RB) {
+            if (bal != 0ull) {  // wave-uniform: an offset no row of the supertile has costs nothing further
+              // ONE store per offset: lanes with a pair write their entry at its compacted slot, the first (-cnt & 15) lanes
+              // without one write the padding behind the entries (there are always enough: cnt > 48 => 64 - cnt = the padding)
+              const int cnt = __popcll(bal);
+              // lanes below this one WITH a pair: two v_mbcnt (no lane mask, no branch); those WITHOUT one are the rest of them
+              const int below = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+              const int pos = present ? below : cnt + lane - below;
+              if ((present || pos < ((cnt + 15) & ~15)) && !(SPS_ABLATE_FE & 64)) eb[cb * 16 + pos] = present ? ((uint32_t)row << 7) | (uint32_t)lane : PX_PAD;
+              const int nch = (cnt + 15) >> 4;
+              kinfo = lane == j ? (uint32_t)cb | ((uint32_t)nch << 16) : kinfo;  // (lane j keeps its offset's first chunk and chunk count)
+              cb += nch;
+            }
           }
         }
       }
     }
-    if (eb) {
-      if (lane < cb) kb[lane] = (unsigned char)(27 * slice + klo);
-      if (lane + 64 < cb) kb[lane + 64] = (unsigned char)(27 * slice + khi);
+    if constexpr (RB) {
+      // chunk -> offset table: lane j < 27 writes the byte of its offset to the offset's 0..4 chunks
+      const int first = (int)(kinfo & 0xFFFFu), nch = lane < 27 ? (int)(kinfo >> 16) : 0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (i < nch) kb[first + i] = (unsigned char)(27 * slice + lane);
+      if (lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = (SPS_ABLATE_FE & 64) ? 0 : cb;  // (ablation bit 6: nothing was stored: no chunks to read)
     }
-    if (want_tm && (lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = m;
-    if (eb && lane == 0) rbc[(size_t)(u >> 6) * 4 + slice] = (SPS_ABLATE_FE & 64) ? 0 : cb;  // (ablation bit 6: nothing was stored: no chunks to read)
+    if (TM && (lane & 15) == 0 && ok) tmask[(size_t)(u >> 4) * 4 + slice] = m;
   }
+}
+
+__device__ inline void build_nbr3(const MapsArgs &a, int bid, int slice) {
+  int local;
+  const int l = level_of_chunk(a, 0, local, bid);
+  const int nchunks = a.chunk_off[l + 1] - a.chunk_off[l];
+  // tile masks say which entries of the neighbour table were written: a level that keeps only the rulebook (inference-only
+  // context, pair-exact layers) needs neither (round 5: five vector instructions per offset less for 87 % of the rows)
+  const bool rb = a.rb_e[l] != nullptr, tm = a.nbr3[l] != nullptr || !rb;
+  if (rb && tm) build_nbr3_t<true, true>(a, l, local, nchunks, slice);
+  else if (rb) build_nbr3_t<false, true>(a, l, local, nchunks, slice);
+  else build_nbr3_t<true, false>(a, l, local, nchunks, slice);
 }
 
 // bit test of a tile mask: 3x3x3x3 maps keep one word per time slice, every other map bit k of the 128-bit field
