@@ -419,6 +419,15 @@ def main():
             traffic, traffic_note = tj["hbm_bytes_per_scan"], tj["method"]
         else:
             traffic_note = "profiles/traffic.json is stale: it was measured with an earlier build of the kernels"
+    # the binding budget (DESIGN: MFMA + VALU time per SIMD and scan, tools/pmc_stalls.sh + vector_pipe_budget.py): attached only
+    # when it was measured on THIS build of the kernels
+    vpipe = {}
+    vp = os.path.join(ROOT, "profiles", "vector_pipe_budget.json")
+    if os.path.exists(vp) and args.config == 2:
+        vj = json.load(open(vp))
+        if vj.get("csrc_sha") == csrc_sha():
+            vpipe = {"vector_pipe_us_per_scan": vj["vector_pipe_us_per_scan"], "vector_pipe_mfma_us": vj["mfma_us"],
+                     "vector_pipe_valu_us": vj["valu_us"]}
     roof = {
         "bound": "hbm", "achieved": round(achieved, 2), "peak": roofline.HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / roofline.HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_note": traffic_note,
@@ -430,6 +439,8 @@ def main():
         "mfma_f32_frac": round(work["flops"] / t_step / 1e12 / roofline.MFMA_F32_PEAK_TFLOPS, 5),
         "dominant_kernel": dom, "largest_traffic_kernel": dom_bytes if stages else None,
         "stage_ms_sum": round(sum(s["ms"] for s in stages), 4), "stages": stages,
+        "vector_pipe_us_per_scan": vpipe.get("vector_pipe_us_per_scan"), "vector_pipe_mfma_us": vpipe.get("vector_pipe_mfma_us"),
+        "vector_pipe_valu_us": vpipe.get("vector_pipe_valu_us"),
     }
     # rocprofv3 kernel durations of the same build (tools/kernel_durations.py, written by tools/collect_evidence.sh): the
     # launches of one forward in order, mapped onto the stages -- kernel time without the launch gaps the hipEvent stages hold

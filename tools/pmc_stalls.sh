@@ -12,4 +12,6 @@ pass 5 TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYC
 pass 6 TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_REQUEST_sum GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES
 python3 tools/pmc_kernels2.py $o/p1 $o/p2 $o/p3 $o/p4 $o/p5 $o/p6 > $o/pmc_stalls.txt 2> $o/agg.err
 rm -rf $o/p1 $o/p2 $o/p3 $o/p4 $o/p5 $o/p6
-head -50 $o/pmc_stalls.txt
+# the budget table + the JSON bench.py attaches to its line (`roofline.vector_pipe_us_per_scan`) for this build
+python3 tools/vector_pipe_budget.py $o/pmc_stalls.txt $o/vector_pipe_budget.txt $o/vector_pipe_budget.json && cp $o/vector_pipe_budget.json profiles/vector_pipe_budget.json
+head -50 $o/vector_pipe_budget.txt
