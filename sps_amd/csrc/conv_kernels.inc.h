@@ -172,11 +172,7 @@ __global__ __launch_bounds__((S == 8 ? 512 : 256) * CG, MINW) void k_conv(ConvAr
     int4 oent = make_int4(0, 0, 0, 0);
     if (a.tile_order && active) {
       int idx = pos;
-      if (a.order_ways > 0) {  // odd tiers run backwards (a last, partial tier is taken as is)
-        const int tier = pos / a.order_ways, c = pos - tier * a.order_ways;
-        const int len = min(a.order_ways, ntiles - tier * a.order_ways);
-        idx = tier * a.order_ways + ((tier & 1) ? len - 1 - c : c);
-      }
+      if (a.order_ways > 0) idx = balanced_index(pos, ntiles, a.order_ways);
       oent = a.tile_order[idx];
       tile = oent.x;
     }

@@ -455,6 +455,31 @@ __global__ void k_count_pairs(const int *__restrict__ nbr, int64_t ldn, int slic
 #define SPS_TILE_ORDER_WAYS 256
 #endif
 constexpr int TILE_ORDER = SPS_TILE_ORDER, TILE_ORDER_WAYS = SPS_TILE_ORDER_WAYS;
+// Which entry of the heaviest-first order the workgroup at position `pos` takes.  n items over `ways` positions that share a CU
+// when the launch has the chip to itself (pos, pos + ways, pos + 2 ways ...): q = n / ways full tiers, and the first r = n % ways
+// ways hold one item MORE (the partial tier q).  Rounds 3-5 dealt the tiers boustrophedon and took the partial tier as it came:
+// the long ways got their extra item on top of a sum that was balanced without it -- busiest way 1.31 x the mean at level 3 with
+// two column groups (317 tiles, 128 ways), 2.04 x with one, 1.17 x at level 1 (667 supertiles), 1.06 x at levels 0 and 2
+// (tools/order_balance_sim.py).  Round 6: every full tier still holds ITS OWN items (the dispatch order stays heaviest-first tier by
+// tier, which is what counts when other kernels share the CUs and placement is dynamic: a rule that moved light items to the
+// front lost 0.5-1.6 % pipelined), but inside a tier the r long ways take the tier's r LIGHTEST items and the other ways its
+// ways - r heaviest, each group boustrophedon across the tiers: 1.12 / 1.57 / 1.09 / 1.03 / 1.06 x.
+#ifndef SPS_ORDER_TIERSPLIT
+#define SPS_ORDER_TIERSPLIT 1
+#endif
+__device__ inline int balanced_index(int pos, int n, int ways) {
+  const int tier = pos / ways, way = pos - tier * ways;
+  if (SPS_ORDER_TIERSPLIT) {
+    const int q = n / ways, r = n - q * ways;
+    if (tier >= q) return pos;  // the partial tier: the lightest items, on the long ways [0, r)
+    if (way < r) return tier * ways + (ways - r) + ((tier & 1) ? r - 1 - way : way);
+    const int wh = ways - r, c = way - r;
+    return tier * ways + ((tier & 1) ? wh - 1 - c : c);
+  }
+  const int len = min(ways, n - tier * ways);  // odd tiers run backwards (a last, partial tier is taken as is)
+  return tier * ways + ((tier & 1) ? len - 1 - way : way);
+}
+
 constexpr int TILE_ORDER_FIRST_LEVEL = 2;
 struct TileOrderArgs {
   const uint32_t *tm3[NLV];
@@ -545,9 +570,7 @@ __device__ inline void px_order_body(const TileOrderArgs &a, int l) {
   }
   __syncthreads();
   for (int p = threadIdx.x; p < nst; p += blockDim.x) {
-    const int tier = p / PX_ORDER_WAYS, c = p - tier * PX_ORDER_WAYS;
-    const int len = min(PX_ORDER_WAYS, nst - tier * PX_ORDER_WAYS);
-    const int st = __hip_atomic_load(sorted + tier * PX_ORDER_WAYS + ((tier & 1) ? len - 1 - c : c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int st = __hip_atomic_load(sorted + balanced_index(p, nst, PX_ORDER_WAYS), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int4 ns = rbc4[st];
     a.px_order[l][p] = make_int4(st, ns.x, ns.y, ns.z);
   }
