@@ -36,6 +36,8 @@ def main():
     if agents:
         gpus = [r for r in csv.DictReader(open(agents[0])) if r.get("Agent_Type") == "GPU"]
         device = (gpus[0].get("Product_Name") or gpus[0].get("Name")) if gpus else None
+        if device and device.strip().lower() in ("unknown", "n/a", ""):
+            device = None
     out = {"csrc_sha": csrc_sha(), "workload": workload, **({"device": device} if device else {}), "scans_averaged": len(scans), "launches": [[nm, round(u, 3)] for nm, u in zip(names, us)],
            "sum_us": round(sum(us), 2),
            "method": "rocprofv3 --kernel-trace over bench.py --streams 1; per launch position the mean duration over the "
