@@ -588,7 +588,7 @@ constexpr int FUSE_UP = SPS_FUSE_UP;
 struct Geometry {
   int ntw, S;
 };
-Geometry conv_geometry(int level, int K, int cin, int nt) {
+Geometry conv_geometry(int level, int K, int cin, int nt, int64_t cap = 0) {
   if (K == 8 && level >= 3) return {std::min(2, nt), 4};  // stride convs into the two coarsest levels: ~100-300 tiles, split four ways
   if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
   (void)cin;
@@ -597,6 +597,19 @@ Geometry conv_geometry(int level, int K, int cin, int nt) {
   // (serial 0.552 -> 0.506 ms) and two column tiles per wave halve the re-gathers of A (pipelined +2.7 % per level
   // group over one column tile per wave, tools/geom_sweep.sh)
   Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{std::min(2, nt), 4};
+#ifndef SPS_GEOM_FEW_TILES
+#define SPS_GEOM_FEW_TILES 0
+#endif
+  // Measured and NOT taken (round 6; the switch is for A/B builds): level 4 holds few tiles (104 at config 2): with two column
+  // tiles per wave a 64-channel layer is 208 workgroups -- fewer than CUs, the launch is its heaviest tile's chain.  ONE column
+  // tile per wave (416 workgroups): block4.conv1 / conv2 10.1 / 15.3 -> 8.1 / 12.0 us, serial forward 366.4 -> 360.0 us
+  // (rocprofv3) -- but the pipelined rate falls 0.7-0.9 % (4 448 -> 4 418 resident, five alternating runs; driver protocol
+  // 3 982 -> 3 942): twice the A gathers for the same MFMAs.  The same at level 3 for the 32-channel layers: -2.4 us serial,
+  // -1.3...-1.8 % pipelined together with level 4.  Latency against throughput, again (LAB 3.1d).
+  if (SPS_GEOM_FEW_TILES && K == 81 && level >= 4 && nt >= 2 && cap > 0) {
+    const int64_t tiles = std::max<int64_t>(1, cap * 11 / 1000 / 16);
+    if (tiles * nt <= 800) g.ntw = 1;
+  }
 #if defined(SPS_DIAG)
   // tuning hook (diagnostics): SPS_GEOM_L<level>="<ntw>,<S>"  column tiles per wave (1, 2, 4; clipped to NT) and splits
   // of the unit list inside the workgroup (1, 2, 4); read once
@@ -709,7 +722,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.inv_upk = cs.cin >= 4 ? 1.0f / (float)cs.upk() : 1.f;
   a.relu = cc.relu;
   a.in_const = 0.5f;  // models.py:22
-  const Geometry g = conv_geometry(cc.level_out, cs.K, cs.cin, a.NT);
+  const Geometry g = conv_geometry(cc.level_out, cs.K, cs.cin, a.NT, (int64_t)c->cap);
   a.S = g.S;
   // expected tiles at this level (rows shrink ~2.5x per level); floor keeps small clouds parallel
   int64_t gx = (c->cap / 64) >> cc.level_out;
