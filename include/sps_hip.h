@@ -78,6 +78,13 @@ int64_t sps_arena_bytes(sps_ctx *ctx);
  * counts from the rulebook, and sps_train_forward switches the context back (re-allocation).  Takes effect at the next
  * reserve / forward (re-allocation: synchronises). */
 int sps_ctx_set_inference_only(sps_ctx *ctx, int on);
+/* How the context's forwards are scheduled -- a hint for the launch geometry, never for the results (bit-identical either way).
+ * on == 0 (default): one forward after another (a plain `model(batch)` loop, the online filter: sps_node.callback handles one scan
+ * at a time, sps_node.py:88-176): the coarse levels, which hold few tiles, run one column tile per wave -- the shortest chain
+ * (serial forward 366 -> 359 us at config 2).  on != 0: forwards of several contexts are in flight beside each other
+ * (sps_amd.engine.ScanEngine with more than one pipeline; no reference counterpart: predict.py:64-67 is one Trainer loop): two
+ * column tiles per wave -- half the gathers for the same MFMAs, +1.3-1.8 % scans/s pipelined.  Takes effect at the next forward. */
+int sps_ctx_set_pipelined(sps_ctx *ctx, int on);
 
 /* ---- weights ------------------------------------------------------------------------
  * Replaces nn.Module.load_state_dict on CustomMinkUNet (reference scripts/predict.py:56-58,

@@ -23,7 +23,7 @@ class SpsError(RuntimeError):
         self.code = code
 
 
-ABI_VERSION = 200          # sps_version() of the library this binding was written against
+ABI_VERSION = 201          # sps_version() of the library this binding was written against
 
 
 def _load() -> C.CDLL:
@@ -55,6 +55,7 @@ def _load() -> C.CDLL:
         "sps_reserve": (i32, [vp, i64]),
         "sps_ctx_set_level_fractions": (i32, [vp, vp]),
         "sps_ctx_set_inference_only": (i32, [vp, i32]),
+        "sps_ctx_set_pipelined": (i32, [vp, i32]),
         "sps_arena_bytes": (i64, [vp]),
         "sps_weights_num_tensors": (i32, []),
         "sps_weights_tensor_info": (i32, [i32, C.c_char_p, i32, C.POINTER(i64), C.POINTER(i64)]),
@@ -120,7 +121,7 @@ def _load() -> C.CDLL:
 
 lib = _load()
 EXPORTS = ["sps_last_error", "sps_version", "sps_ctx_create", "sps_ctx_destroy", "sps_reserve",
-           "sps_ctx_set_level_fractions", "sps_ctx_set_inference_only", "sps_arena_bytes",
+           "sps_ctx_set_level_fractions", "sps_ctx_set_inference_only", "sps_ctx_set_pipelined", "sps_arena_bytes",
            "sps_weights_num_tensors", "sps_weights_tensor_info", "sps_weights_numel", "sps_weights_load",
            "sps_weights_create", "sps_weights_destroy", "sps_ctx_set_weights",
            "sps_forward", "sps_forward_metrics", "sps_head_num_tensors", "sps_head_tensor_info", "sps_head_numel", "sps_weights_load_head",
@@ -216,6 +217,11 @@ class Context:
         """Inference-only context (include/sps_hip.h): at the pair-exact levels the rulebook replaces the neighbour table
         (less arena, fewer bytes written per scan); training on the context switches it back."""
         check(lib.sps_ctx_set_inference_only(self.handle, 1 if on else 0))
+
+    def set_pipelined(self, on: bool = True):
+        """Launch-geometry hint (include/sps_hip.h): True = forwards of several contexts run beside each other (least work per
+        forward), False (default) = one forward after another (shortest chain).  Results are bit-identical either way."""
+        check(lib.sps_ctx_set_pipelined(self.handle, 1 if on else 0))
 
     def arena_bytes(self) -> int:
         return int(lib.sps_arena_bytes(self.handle))

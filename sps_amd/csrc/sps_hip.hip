@@ -240,6 +240,9 @@ struct sps_ctx {
   // inference-only context (sps_ctx_set_inference_only): at the levels whose layers run pair-exact the rulebook takes
   // the place (and the memory) of the neighbour table, which is neither written nor kept -- no training, no sps_get_nbr
   bool lean = false;
+  // sps_ctx_set_pipelined: the context's forwards run BESIDE other contexts' forwards (ScanEngine with several pipelines): the
+  // launch geometry that does the least work; off (default): one forward after another -- the geometry with the shortest chain
+  bool pipelined = false;
   uint64_t arena_gen = 0;  // bumped by every (re)allocation of the arena: dependants (training views) re-derive their pointers
   int64_t last_n = 0;    // points of the last forward
   uint64_t fwd_gen = 0;  // bumped by every forward: what the activations / maps held by the context belong to
@@ -588,7 +591,7 @@ constexpr int FUSE_UP = SPS_FUSE_UP;
 struct Geometry {
   int ntw, S;
 };
-Geometry conv_geometry(int level, int K, int cin, int nt, int64_t cap = 0) {
+Geometry conv_geometry(int level, int K, int cin, int nt, int64_t cap = 0, bool serial_chain = false) {
   if (K == 8 && level >= 3) return {std::min(2, nt), 4};  // stride convs into the two coarsest levels: ~100-300 tiles, split four ways
   if (K == 1 || K == 8) return {nt <= 2 ? nt : 1, 1};
   (void)cin;
@@ -597,17 +600,17 @@ Geometry conv_geometry(int level, int K, int cin, int nt, int64_t cap = 0) {
   // (serial 0.552 -> 0.506 ms) and two column tiles per wave halve the re-gathers of A (pipelined +2.7 % per level
   // group over one column tile per wave, tools/geom_sweep.sh)
   Geometry g = level <= 1 ? Geometry{nt, 1} : Geometry{std::min(2, nt), 4};
-#ifndef SPS_GEOM_FEW_TILES
-#define SPS_GEOM_FEW_TILES 0
-#endif
-  // Measured and NOT taken (round 6; the switch is for A/B builds): level 4 holds few tiles (104 at config 2): with two column
-  // tiles per wave a 64-channel layer is 208 workgroups -- fewer than CUs, the launch is its heaviest tile's chain.  ONE column
-  // tile per wave (416 workgroups): block4.conv1 / conv2 10.1 / 15.3 -> 8.1 / 12.0 us, serial forward 366.4 -> 360.0 us
-  // (rocprofv3) -- but the pipelined rate falls 0.7-0.9 % (4 448 -> 4 418 resident, five alternating runs; driver protocol
-  // 3 982 -> 3 942): twice the A gathers for the same MFMAs.  The same at level 3 for the 32-channel layers: -2.4 us serial,
-  // -1.3...-1.8 % pipelined together with level 4.  Latency against throughput, again (LAB 3.1d).
-  if (SPS_GEOM_FEW_TILES && K == 81 && level >= 4 && nt >= 2 && cap > 0) {
-    const int64_t tiles = std::max<int64_t>(1, cap * 11 / 1000 / 16);
+  // Levels 3-4 hold few tiles (a LiDAR cloud of n points: ~n / 30 and ~n / 90 rows; 317 and 104 tiles at config 2): with two
+  // column tiles per wave a 32-channel layer of level 3 is 317 workgroups, a 64-channel layer of level 4 is 208 -- about one per
+  // CU, and the launch is its heaviest tile's chain.  ONE column tile per wave where (expected tiles x column tiles) stays below
+  // ~800 workgroups shortens the chain: block4.conv1 / conv2 10.1 / 15.3 -> 8.1 / 12.0 us, block3.conv1 / conv2 8.2 / 10.5 ->
+  // 6.7 / 9.6 us, serial forward 365.9 -> 359.3 us (rocprofv3) -- at twice the A gathers for the same MFMAs: forwards in flight
+  // BESIDE each other lose 1.3-1.8 % (4 445 -> 4 388 scans/s; level 4 alone: -0.7 %).  So it is the geometry of a context whose
+  // forwards run one after another (`serial_chain`: the default; sps_ctx_set_pipelined(ctx, 1) turns it off -- ScanEngine with
+  // several pipelines does).  Beyond ~800 workgroups the finer grain loses serially too (block5 with four column groups:
+  // 22.8 / 18.4 -> 28.6 / 22.4 us).  Same per-element summation order either way: bit-identical results.
+  if (serial_chain && K == 81 && level >= 3 && nt >= 2 && cap > 0) {
+    const int64_t tiles = std::max<int64_t>(1, cap * (level == 3 ? 33 : 11) / 1000 / 16);
     if (tiles * nt <= 800) g.ntw = 1;
   }
 #if defined(SPS_DIAG)
@@ -722,7 +725,7 @@ int run_conv(sps_ctx *c, const ConvCall &cc, hipStream_t st) {
   a.inv_upk = cs.cin >= 4 ? 1.0f / (float)cs.upk() : 1.f;
   a.relu = cc.relu;
   a.in_const = 0.5f;  // models.py:22
-  const Geometry g = conv_geometry(cc.level_out, cs.K, cs.cin, a.NT, (int64_t)c->cap);
+  const Geometry g = conv_geometry(cc.level_out, cs.K, cs.cin, a.NT, (int64_t)c->cap, !c->pipelined);
   a.S = g.S;
   // expected tiles at this level (rows shrink ~2.5x per level); floor keeps small clouds parallel
   int64_t gx = (c->cap / 64) >> cc.level_out;
@@ -989,7 +992,7 @@ int transform_launch(const TIN *in, int64_t ld, int64_t n, const Mat4 &T, int id
 extern "C" {
 
 const char *sps_last_error(void) { return g_err.c_str(); }
-int sps_version(void) { return 200; }
+int sps_version(void) { return 201; }
 
 int sps_ctx_create(int device, sps_ctx **out) {
   if (!out) return fail(SPS_ERR_INVALID, "out is null");
@@ -1584,6 +1587,12 @@ int sps_ctx_set_inference_only(sps_ctx *c, int on) {
     c->lean = lean;
     if (c->cap > 0) c->regrow = true;  // re-allocated by the next reserve / forward
   }
+  return SPS_OK;
+}
+
+int sps_ctx_set_pipelined(sps_ctx *c, int on) {
+  if (!c) return fail(SPS_ERR_INVALID, "ctx is null");
+  c->pipelined = on != 0;  // (launch geometry only: takes effect at the next forward, nothing is re-allocated)
   return SPS_OK;
 }
 

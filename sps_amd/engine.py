@@ -63,6 +63,8 @@ class ScanEngine:
         # the engine only runs inference: the rulebook replaces the neighbour table where the layers run pair-exact
         for cx in self.ctxs:
             cx.set_inference_only(True)
+            # several forwards in flight: the geometry that does the least work; a single pipeline keeps the shortest chain
+            cx.set_pipelined(S > 1)
         self._next = 0
         self._stage = [None] * S          # per-stream PAIR of device staging buffers for host batches
         self._pinned = [None] * S         # (pageable host batches only: pinned bounce buffers)

@@ -167,6 +167,25 @@ def test_small_scene_full_parity(net, params):
     check_full(net, params, synthetic.small_scene(seed=0, n_scan=2000), both_classes=True)
 
 
+def test_launch_geometry_hint_does_not_change_a_bit(net, params):
+    """sps_ctx_set_pipelined: one column tile per wave at the coarse levels (a context whose forwards run one after another,
+    the default) or two (several contexts in flight: ScanEngine) -- the per-element summation order is the same, so scores
+    and every tapped feature map are bit-identical; the engine's pipelines agree with a direct call for the same reason."""
+    batch = synthetic.make_scene(scan_seed=3, n_azimuth=500)["batch"]        # LiDAR-like: levels 3 and 4 hold few tiles
+    out = {}
+    try:
+        for mode in (False, True):
+            ctx().set_pipelined(mode)
+            _, scores = run(net, batch)
+            out[mode] = (scores.clone(), {n: get_feature(n) for n in ("block3", "block4", "block5", "block8")})
+    finally:
+        ctx().set_pipelined(False)
+    assert torch.equal(out[False][0], out[True][0])
+    for n, f in out[False][1].items():
+        np.testing.assert_array_equal(f, out[True][1][n], err_msg=n)
+    assert float(out[False][0].min()) >= 0 and not torch.isnan(out[False][0]).any()
+
+
 def test_other_seed_and_default_bn(params):
     p = O.random_params(seed=7, randomize_bn=False)
     n = net_from_params(p).cuda().eval().freeze()
