@@ -185,6 +185,10 @@ def main():
                          "pipeline counts that are multiples of 4 load the queues evenly (DESIGN.md section 3.2).  Default 8; "
                          "runs of fewer than 40 steps use 4 so that every pipeline executes several timed steps")
     ap.add_argument("--side-streams-only", action="store_true", help="DIAGNOSTIC: the current stream is NOT one of the --streams pipelines (round 4's engine)")
+    ap.add_argument("--pipelined-geometry", action="store_true",
+                    help="DIAGNOSTIC: with --streams 1 keep the launch geometry of the several-pipelines engine (sps_ctx_set_pipelined): "
+                         "what the rocprofv3 / counter passes of tools/collect_evidence.sh run, so that their per-kernel numbers "
+                         "describe the kernels of the headline run")
     ap.add_argument("--exact-streams", action="store_true", help="DIAGNOSTIC: use exactly --streams streams even for short runs")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only for "
                     "exercising the multi-rank control flow on a single GPU)")
@@ -267,7 +271,7 @@ def main():
         from sps_amd.engine import SHORT_RUN_STREAMS
         S = SHORT_RUN_STREAMS if (args.streams >= SHORT_RUN_STREAMS and K >= 2 * SHORT_RUN_STREAMS) else 2
     eng = ScanEngine(net, dev, streams=S, max_rows=max_rows, table_rows=K * nb, stage_cols=0 if args.no_h2d else 6,
-                     include_main=not args.side_streams_only)
+                     include_main=not args.side_streams_only, pipelined=True if args.pipelined_geometry else None)
     streams = eng.streams
     main_stream = eng.main
 

@@ -33,7 +33,8 @@ SHORT_RUN_STREAMS = 4
 
 class ScanEngine:
     def __init__(self, net: SPSNet, device: torch.device | int | None = None, streams: int = DEFAULT_STREAMS,
-                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0, compact: bool = True, include_main: bool = True):
+                 max_rows: int = 0, table_rows: int = 0, stage_cols: int = 0, compact: bool = True, include_main: bool = True,
+                 pipelined: bool | None = None):
         if device is None:
             device = torch.cuda.current_device()
         self.device = torch.device("cuda", device) if isinstance(device, int) else torch.device(device)
@@ -64,7 +65,8 @@ class ScanEngine:
         for cx in self.ctxs:
             cx.set_inference_only(True)
             # several forwards in flight: the geometry that does the least work; a single pipeline keeps the shortest chain
-            cx.set_pipelined(S > 1)
+            # (`pipelined` overrides: profiling passes run ONE stream with the kernels exactly as the pipelines launch them)
+            cx.set_pipelined(S > 1 if pipelined is None else bool(pipelined))
         self._next = 0
         self._stage = [None] * S          # per-stream PAIR of device staging buffers for host batches
         self._pinned = [None] * S         # (pageable host batches only: pinned bounce buffers)

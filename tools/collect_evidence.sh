@@ -14,7 +14,7 @@ o=gpurun_out/$tag; mkdir -p $o
 : >> $o/bench.err
 if [ "$phase" != bench ]; then
 for ctr in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $o/pmc_$ctr -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
+  rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $o/pmc_$ctr -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 --pipelined-geometry > /dev/null 2>> $o/bench.err
 done
 # the tracked profiles/traffic.json (what `roofline.traffic` of every later bench line reports) is replaced only by a
 # complete measurement of this build: both passes present and the derivation successful
@@ -24,7 +24,7 @@ else
   echo "traffic_pmc.py failed: profiles/traffic.json left as it was" | tee -a $o/bench.err
 fi
 # rocprofv3 kernel durations of this build first: the bench lines below then carry `dominant_kernel_rocprof_us`
-rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_serial -- python3 bench.py --streams 1 --steps 80 --warmup 10 --no-cpu-baseline --no-h2d > $o/bench_under_rocprof_serial.json 2>> $o/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_serial -- python3 bench.py --streams 1 --pipelined-geometry --steps 80 --warmup 10 --no-cpu-baseline --no-h2d > $o/bench_under_rocprof_serial.json 2>> $o/bench.err
 if python3 tools/kernel_durations.py $o/prof_serial $o/kernel_durations.json >> $o/traffic_summary.txt 2>> $o/bench.err && [ -s $o/kernel_durations.json ]; then
   cp $o/kernel_durations.json profiles/kernel_durations.json
 fi
@@ -45,12 +45,12 @@ python3 bench.py --config 4 --steps 150 --warmup 20 > $o/bench_config4.json 2>> 
 rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_pipelined -- python3 bench.py --steps 150 --warmup 20 --no-cpu-baseline --no-stages --no-h2d > $o/bench_under_rocprof_pipelined.json 2>> $o/bench.err
 cp $(ls $o/prof_pipelined/*/*kernel_stats.csv | head -1) $o/kernel_stats_pipelined.csv
 if [ ! -f $o/kernel_trace_serial.csv ]; then   # (phase `bench` on a box of its own: the serial trace overlap.py compares with)
-  rocprofv3 --kernel-trace --output-format csv -d $o/prof_serial2 -- python3 bench.py --streams 1 --steps 40 --warmup 10 --no-cpu-baseline --no-h2d --no-stages > /dev/null 2>> $o/bench.err
+  rocprofv3 --kernel-trace --output-format csv -d $o/prof_serial2 -- python3 bench.py --streams 1 --pipelined-geometry --steps 40 --warmup 10 --no-cpu-baseline --no-h2d --no-stages > /dev/null 2>> $o/bench.err
   cp $(ls $o/prof_serial2/*/*kernel_trace.csv | head -1) $o/kernel_trace_serial.csv; rm -rf $o/prof_serial2
 fi
 python3 tools/overlap.py $(ls $o/prof_pipelined/*/*kernel_trace.csv | head -1) $o/kernel_trace_serial.csv > $o/overlap.txt
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $o/pmc_a -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $o/pmc_b -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 > /dev/null 2>> $o/bench.err
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $o/pmc_a -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 --pipelined-geometry > /dev/null 2>> $o/bench.err
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES TA_TA_BUSY_sum TCP_TCC_READ_REQ_sum TAL_CACHE_ACCESSES_sum --kernel-trace --output-format csv -d $o/pmc_b -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-stages --no-h2d --streams 1 --pipelined-geometry > /dev/null 2>> $o/bench.err
 python3 tools/pmc_table.py $o/pmc_a $o/pmc_b > $o/pmc_conv_layers.txt 2>> $o/bench.err
 python3 tools/pmc_derive.py $o/pmc_conv_layers.txt > $o/pmc_conv_layers_derived.txt 2>> $o/bench.err
 python3 tools/train_timing.py --steps 50 2>> $o/bench.err | tail -1 > $o/train_timing.txt
